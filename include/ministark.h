@@ -1,0 +1,139 @@
+/* ministark.h — C ABI of the MI355X-native backend for mini-stark's
+ * low-degree-extension + FRI + Merkle proving path.
+ *
+ * The reference (alv-around/mini-stark, Rust on arkworks) has no FFI; the seams
+ * this ABI sits behind are `Stark::prove` (src/starks.rs:59-169), `Fri::prove`
+ * (src/fri.rs:53-189), the `Tree` trait (src/merkle.rs:8-30) and the arkworks
+ * calls they make.  One function per transcript-delimited stage, so the
+ * Fiat–Shamir transcript (nimue) stays with the caller: every challenge is an
+ * INPUT and every commitment / opened value an OUTPUT.  INTEGRATION.md shows the
+ * Rust `extern "C"` block and the patched `prove` that binds these symbols.
+ *
+ * Conventions
+ *  - Field elements cross the boundary as canonical little-endian u64 limbs
+ *    (`Fp::into_bigint()`), also for BabyBear (the reference stores one u64
+ *    limb for both fields, src/field.rs:47,76).  Extension elements are E
+ *    consecutive limbs: Goldilocks Fp2 = (c0, c1); BabyBear Fp4 =
+ *    (c0.c0, c0.c1, c1.c0, c1.c1)  (src/field.rs:50-109).
+ *  - Digests are 32 raw SHA-256 bytes (`Hash<Sha256>`, src/lib.rs:13).
+ *  - Every function returns MS_OK or a negative ms_status; nothing unwinds.
+ *    Conditions on which the reference panics/asserts map to MS_ERR_SHAPE
+ *    (src/merkle.rs:93-104, src/air.rs:23-26,53-54, src/starks.rs:317-320);
+ *    src/error.rs:13-21 maps to MS_ERR_LEAF_NOT_FOUND / MS_ERR_OUT_OF_RANGE.
+ *  - Blocking calls; one ms_ctx per host thread and per GPU (the reference is
+ *    single-threaded, `Stark::prove(&self)`); not thread-safe.
+ *  - Host buffers are caller-owned and only read/written during the call.
+ *    Large intermediates (polynomials, LDE, trees, FRI rounds) stay in HBM
+ *    inside the context until the next proof or ms_destroy.
+ */
+#ifndef MINISTARK_H
+#define MINISTARK_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ms_ctx ms_ctx;
+
+typedef enum { MS_FIELD_GOLDILOCKS = 0, MS_FIELD_BABYBEAR = 1 } ms_field; /* src/field.rs:36-76 */
+
+typedef enum {
+  MS_OK = 0,
+  MS_ERR_SHAPE = -1,          /* reference assert!/panic */
+  MS_ERR_LEAF_NOT_FOUND = -2, /* MerkleProofError::LeafNotFound, src/error.rs:15-18 */
+  MS_ERR_OUT_OF_RANGE = -3,   /* MerkleProofError::OutOfRangeError, src/error.rs:19-21 */
+  MS_ERR_STATE = -4,          /* stage called out of order */
+  MS_ERR_ARG = -5,            /* null pointer, non-canonical element, unsupported parameter */
+  MS_ERR_HIP = -6,            /* HIP runtime failure; see ms_last_error */
+  MS_ERR_NOMEM = -7
+} ms_status;
+
+/* flags for ms_create */
+#define MS_FLAG_ZERO_DISPLAY_EMPTY 0x1u /* ark-ff Display prints ZERO as "" (default behaviour of ark-ff 0.5.0) */
+#define MS_FLAGS_DEFAULT MS_FLAG_ZERO_DISPLAY_EMPTY
+
+/* ---- context ------------------------------------------------------------ */
+int ms_create(ms_ctx** out, int device, ms_field field, uint32_t flags);
+void ms_destroy(ms_ctx* ctx);
+const char* ms_last_error(const ms_ctx* ctx);
+int ms_ext_degree(const ms_ctx* ctx);             /* 2 (Goldilocks) / 4 (BabyBear): StarkField::Extension */
+int ms_set_stream(ms_ctx* ctx, void* hip_stream); /* run on a caller-owned hipStream_t (NULL: back to the ctx's own) */
+int ms_synchronize(ms_ctx* ctx);
+
+/* ---- src/util.rs:4-44, src/starks.rs:268-332 (host-only config math) ----- */
+int ms_is_power_of_two(uint64_t n);
+long ms_logarithm_of_two_k(uint64_t n, uint64_t base); /* -1: not a power of 2, -2: not a power of base */
+uint64_t ms_ceil_log2_k(uint64_t n, uint64_t base);
+int ms_num_queries(ms_field f, uint64_t security_bits, uint64_t blowup, uint64_t steps,
+                   uint64_t* linking_queries, uint64_t* fri_queries_per_round); /* starks.rs:312-332 */
+uint64_t ms_root_of_unity(ms_field f, uint64_t n); /* Radix2EvaluationDomain::new(n).group_gen  (TraceTable::omega, air.rs:75) */
+
+/* ---- Stark::prove stages (src/starks.rs:59-169) --------------------------- */
+/* 1.1  MerkleTree::new(trace.get_data(), lpn) -> root.  starks.rs:68-73, air.rs:15-59.
+ *      `trace` is the N x w row-major matrix (N a power of two).  Also uploads the trace. */
+int ms_trace_commit(ms_ctx* ctx, const uint64_t* trace_rowmajor, size_t N, size_t w, size_t lpn, uint8_t root[32]);
+/*      Same, for a trace already resident in HBM (device pointer, same layout). */
+int ms_trace_commit_device(ms_ctx* ctx, const void* d_trace_rowmajor, size_t N, size_t w, size_t lpn, uint8_t root[32]);
+/* 1.2a TraceTable::get_trace_polys: per-column INTT.  air.rs:147-160. */
+int ms_interpolate(ms_ctx* ctx);
+/* 1.2b constraint polynomial appended as sum_t scalars[t] * poly[idx[t]] (the
+ *      closures of tests/e2e_goldilocks.rs:48-59 are such combinations), or
+ *      uploaded verbatim (N canonical coefficients).  air.rs:127-144. */
+int ms_polys_lincomb(ms_ctx* ctx, const uint64_t* scalars, const int* idx, int k);
+int ms_polys_append(ms_ctx* ctx, const uint64_t* coeffs, size_t n);
+int ms_polys_count(const ms_ctx* ctx);
+int ms_poly_read(ms_ctx* ctx, int i, uint64_t* out /* N */);
+/* 1.2c coset LDE of every constraint polynomial over Radix2(blowup*N).get_coset(shift)
+ *      and MerkleTree::new over the L x c row-major LDE matrix.  starks.rs:80-95. */
+int ms_lde_commit(ms_ctx* ctx, size_t blowup, uint64_t shift, size_t lpn, uint8_t root[32]);
+int ms_lde_read(ms_ctx* ctx, uint64_t* out_rowmajor /* L*c */);
+/* 1.3  validity = sum_i r^i f_i (remainder of divide_by_vanishing_poly; quirk Q1).  starks.rs:108-119. */
+int ms_mix(ms_ctx* ctx, uint64_t r);
+int ms_validity_read(ms_ctx* ctx, uint64_t* out /* N */);
+/* 2.   DEEP-ALI: out[t][i] = f_i(z_t) for the c constraint polys, out[t][c] = validity(z_t);
+ *      z: q*E limbs, out: q*(c+1)*E limbs.  starks.rs:124-151, field.rs:23-32. */
+int ms_eval_ext(ms_ctx* ctx, const uint64_t* z, int q, uint64_t* out);
+
+/* ---- Fri::prove stages (src/fri.rs:53-189) -------------------------------- */
+/* commit phase, round 0: FriRound::new(extend(validity), (deg+1)*blowup).  fri.rs:73-82, 314-352.
+ * (root0 is returned for inspection; the reference never writes it to the transcript.) */
+int ms_fri_begin(ms_ctx* ctx, size_t blowup, size_t rounds, uint8_t root0[32]);
+/* z -> B = [even(z), odd(z)] (2*E limbs).  fri.rs:89-94, 354-359. */
+int ms_fri_deep(ms_ctx* ctx, const uint64_t* z, uint64_t* B);
+/* alpha -> fold, DEEP quotient (folded - B(alpha))/(x - z), next FriRound, root.  fri.rs:96-109. */
+int ms_fri_fold_commit(ms_ctx* ctx, const uint64_t* alpha, uint8_t root[32]);
+int ms_fri_round_info(ms_ctx* ctx, int round, uint64_t* ncoef, uint64_t* domain_size);
+int ms_fri_round_poly_read(ms_ctx* ctx, int round, uint64_t* out /* ncoef*E */);
+int ms_fri_round_codeword_read(ms_ctx* ctx, int round, uint64_t* out /* D*E */);
+/* query phase for `nq` betas (already converted from challenge bytes to u64, fri.rs:121-126).
+ * Builds the serialised FriProof ("MSFP" layout below) in HBM.  fri.rs:115-189. */
+int ms_fri_query(ms_ctx* ctx, const uint64_t* betas, int nq);
+size_t ms_fri_proof_size(const ms_ctx* ctx);
+int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out);
+/* MSFP layout — for each window (previous, round) in order, for each beta in order:
+ *     6*E u64   x1 y1 x2 y2 x3 y3                      (FriProof.points,    fri.rs:148-154)
+ *     u64 qlen, qlen*E u64 quotient coefficients       (FriProof.quotients, fri.rs:159-167)
+ *     MerklePath(y1), MerklePath(y2)                   (FriProof.queries,   fri.rs:170-172)
+ * MerklePath = u64 leaf_index | lpn*E u64 leaf_neighbours | u64 nlevels | nlevels*ic*32 bytes
+ *              (merkle.rs:272-298; leaf located BY VALUE, first match, quirk Q7). */
+
+/* ---- Tree trait (src/merkle.rs:8-30) on its own -------------------------- */
+/* MerkleTree::new over `leaf_num` elements of `ext` limbs each; writes all nodes
+ * (level-major, root last) if nodes_out != NULL.  ext in {1, E}. */
+int ms_merkle_commit(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic,
+                     uint8_t* nodes_out, size_t nodes_cap, size_t* nnodes, uint8_t root[32]);
+
+/* ---- standalone transforms (NTT micro-benchmark + parity tests) ---------- */
+/* `batch` vectors of n elements each, contiguous; natural order in and out. */
+int ms_ntt(ms_ctx* ctx, uint64_t* data, size_t n, size_t batch, int inverse);
+/* out[b][i] = P_b(shift * g_L^i): coeffs [batch][ncoef] -> out [batch][L]. */
+int ms_coset_lde(ms_ctx* ctx, const uint64_t* coeffs, size_t ncoef, size_t batch, uint64_t shift, uint64_t* out, size_t L);
+/* device-resident benchmark entry: runs the LDE stage of the current session again
+ * (no host copies); used by bench.py to time the NTT kernels in isolation. */
+int ms_bench_lde(ms_ctx* ctx, size_t blowup, uint64_t shift);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

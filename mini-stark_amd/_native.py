@@ -1,0 +1,265 @@
+"""ctypes binding of include/ministark.h (libministark.so, HIP/gfx950).
+
+Plumbing only: numpy arrays in, numpy arrays / bytes out.  The library is the
+product; if it is missing or fails to load this module raises — there is no CPU
+fallback (tests may pass an explicit `lib_path` to exercise the CPU *emulation
+build of the same kernel code*, tests/emu, which the product never loads).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+GOLDILOCKS, BABYBEAR = 0, 1
+FLAG_ZERO_DISPLAY_EMPTY = 1
+OK, ERR_SHAPE, ERR_LEAF_NOT_FOUND, ERR_OUT_OF_RANGE, ERR_STATE, ERR_ARG, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+_LIBS = {}
+
+
+class MsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ministark error {code}: {msg}")
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "libministark.so")
+
+
+def build_library(force=False):
+    """hipcc cross-compile for gfx950 (works without a GPU)."""
+    so = library_path()
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "ministark.h"))
+    if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
+        return so
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
+           os.path.join(_HERE, "csrc", "ministark.cpp"), "-o", so]
+    subprocess.check_call(cmd)
+    return so
+
+
+def load_library(path=None):
+    path = path or library_path()
+    if path in _LIBS:
+        return _LIBS[path]
+    if not os.path.exists(path):
+        raise MsError(ERR_HIP, f"{path} not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(path)
+    L.ms_last_error.restype = C.c_char_p
+    L.ms_last_error.argtypes = [C.c_void_p]
+    L.ms_fri_proof_size.restype = C.c_size_t
+    L.ms_fri_proof_size.argtypes = [C.c_void_p]
+    L.ms_root_of_unity.restype = C.c_uint64
+    L.ms_ceil_log2_k.restype = C.c_uint64
+    L.ms_logarithm_of_two_k.restype = C.c_long
+    _LIBS[path] = L
+    return L
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(_u64p)
+
+
+class Context:
+    """One ms_ctx: a prover session on one GPU (include/ministark.h)."""
+
+    def __init__(self, field=GOLDILOCKS, device=0, flags=FLAG_ZERO_DISPLAY_EMPTY, lib_path=None):
+        self.L = load_library(lib_path)
+        self.field = field
+        h = C.c_void_p()
+        rc = self.L.ms_create(C.byref(h), C.c_int(device), C.c_int(field), C.c_uint32(flags))
+        if rc != 0:
+            raise MsError(rc, "ms_create failed (no usable GPU / HIP runtime?)")
+        self.h = h
+        self.e = self.L.ms_ext_degree(self.h)
+        self.N = self.w = self.Lsize = 0
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.ms_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return (self.L.ms_last_error(self.h) or b"").decode()
+
+    def check(self, rc):
+        if rc != 0:
+            raise MsError(rc, self.last_error())
+
+    # ---- host-only config math -------------------------------------------------
+    def root_of_unity(self, n):
+        return int(self.L.ms_root_of_unity(C.c_int(self.field), C.c_uint64(n)))
+
+    def ceil_log2_k(self, n, base=2):
+        return int(self.L.ms_ceil_log2_k(C.c_uint64(n), C.c_uint64(base)))
+
+    def num_queries(self, security_bits, blowup, steps):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        rc = self.L.ms_num_queries(C.c_int(self.field), C.c_uint64(security_bits), C.c_uint64(blowup), C.c_uint64(steps), C.byref(a), C.byref(b))
+        return rc, a.value, b.value
+
+    def set_stream(self, hip_stream_ptr):
+        self.check(self.L.ms_set_stream(self.h, C.c_void_p(hip_stream_ptr)))
+
+    def synchronize(self):
+        self.check(self.L.ms_synchronize(self.h))
+
+    # ---- Stark::prove stages ---------------------------------------------------
+    def trace_commit(self, trace, lpn):
+        t = np.ascontiguousarray(trace, dtype=np.uint64)
+        N, w = t.shape
+        root = (C.c_uint8 * 32)()
+        rc = self.L.ms_trace_commit(self.h, t.ctypes.data_as(_u64p), C.c_size_t(N), C.c_size_t(w), C.c_size_t(lpn), root)
+        if rc == 0:
+            self.N, self.w = N, w
+        return rc, bytes(root)
+
+    def trace_commit_device(self, dev_ptr, N, w, lpn):
+        root = (C.c_uint8 * 32)()
+        rc = self.L.ms_trace_commit_device(self.h, C.c_void_p(dev_ptr), C.c_size_t(N), C.c_size_t(w), C.c_size_t(lpn), root)
+        if rc == 0:
+            self.N, self.w = N, w
+        return rc, bytes(root)
+
+    def interpolate(self):
+        return self.L.ms_interpolate(self.h)
+
+    def polys_lincomb(self, scalars, idx):
+        s, sp = _u64(scalars)
+        i = np.ascontiguousarray(idx, dtype=np.int32)
+        return self.L.ms_polys_lincomb(self.h, sp, i.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(len(i)))
+
+    def polys_append(self, coeffs):
+        c, cp = _u64(coeffs)
+        return self.L.ms_polys_append(self.h, cp, C.c_size_t(c.size))
+
+    def polys_count(self):
+        return self.L.ms_polys_count(self.h)
+
+    def poly_read(self, i):
+        out = np.zeros(self.N, dtype=np.uint64)
+        self.check(self.L.ms_poly_read(self.h, C.c_int(i), out.ctypes.data_as(_u64p)))
+        return out
+
+    def lde_commit(self, blowup, shift, lpn):
+        root = (C.c_uint8 * 32)()
+        rc = self.L.ms_lde_commit(self.h, C.c_size_t(blowup), C.c_uint64(shift), C.c_size_t(lpn), root)
+        if rc == 0:
+            self.Lsize = self.N * blowup
+        return rc, bytes(root)
+
+    def bench_lde(self, blowup, shift):
+        return self.L.ms_bench_lde(self.h, C.c_size_t(blowup), C.c_uint64(shift))
+
+    def lde_read(self):
+        out = np.zeros((self.Lsize, self.polys_count()), dtype=np.uint64)
+        self.check(self.L.ms_lde_read(self.h, out.ctypes.data_as(_u64p)))
+        return out
+
+    def mix(self, r):
+        return self.L.ms_mix(self.h, C.c_uint64(r))
+
+    def validity_read(self):
+        out = np.zeros(self.N, dtype=np.uint64)
+        self.check(self.L.ms_validity_read(self.h, out.ctypes.data_as(_u64p)))
+        return out
+
+    def eval_ext(self, z):
+        z, zp = _u64(z)
+        q = z.size // self.e
+        out = np.zeros((q, self.polys_count() + 1, self.e), dtype=np.uint64)
+        rc = self.L.ms_eval_ext(self.h, zp, C.c_int(q), out.ctypes.data_as(_u64p))
+        return rc, out
+
+    # ---- Fri::prove stages -------------------------------------------------------
+    def fri_begin(self, blowup, rounds):
+        root = (C.c_uint8 * 32)()
+        rc = self.L.ms_fri_begin(self.h, C.c_size_t(blowup), C.c_size_t(rounds), root)
+        return rc, bytes(root)
+
+    def fri_deep(self, z):
+        z, zp = _u64(z)
+        B = np.zeros(2 * self.e, dtype=np.uint64)
+        rc = self.L.ms_fri_deep(self.h, zp, B.ctypes.data_as(_u64p))
+        return rc, B
+
+    def fri_fold_commit(self, alpha):
+        a, ap = _u64(alpha)
+        root = (C.c_uint8 * 32)()
+        rc = self.L.ms_fri_fold_commit(self.h, ap, root)
+        return rc, bytes(root)
+
+    def fri_round_info(self, r):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.check(self.L.ms_fri_round_info(self.h, C.c_int(r), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def fri_round_poly(self, r):
+        n, _ = self.fri_round_info(r)
+        out = np.zeros((n, self.e), dtype=np.uint64)
+        if n:
+            self.check(self.L.ms_fri_round_poly_read(self.h, C.c_int(r), out.ctypes.data_as(_u64p)))
+        return out
+
+    def fri_round_codeword(self, r):
+        _, D = self.fri_round_info(r)
+        out = np.zeros((D, self.e), dtype=np.uint64)
+        self.check(self.L.ms_fri_round_codeword_read(self.h, C.c_int(r), out.ctypes.data_as(_u64p)))
+        return out
+
+    def fri_query(self, betas, read=True):
+        b, bp = _u64(betas)
+        rc = self.L.ms_fri_query(self.h, bp, C.c_int(b.size))
+        if rc != 0 or not read:
+            return rc, None
+        return 0, self.fri_proof_read()
+
+    def fri_proof_size(self):
+        return int(self.L.ms_fri_proof_size(self.h))
+
+    def fri_proof_read(self):
+        n = self.fri_proof_size()
+        buf = np.zeros(max(1, n), dtype=np.uint8)
+        self.check(self.L.ms_fri_proof_read(self.h, buf.ctypes.data_as(_u8p)))
+        return buf[:n].tobytes()
+
+    # ---- standalone ----------------------------------------------------------------
+    def merkle_commit(self, leafs, ext=1, lpn=2, ic=2):
+        a, p = _u64(leafs)
+        leaf_num = a.size // ext
+        cap = max(1, 2 * leaf_num)
+        nodes = np.zeros((cap, 32), dtype=np.uint8)
+        nn = C.c_size_t(0)
+        root = (C.c_uint8 * 32)()
+        rc = self.L.ms_merkle_commit(self.h, p, C.c_size_t(leaf_num), C.c_int(ext), C.c_size_t(lpn), C.c_size_t(ic),
+                                     nodes.ctypes.data_as(_u8p), C.c_size_t(cap), C.byref(nn), root)
+        if rc != 0:
+            return rc, None, None
+        return 0, nodes[: nn.value].copy(), bytes(root)
+
+    def ntt(self, data, inverse=False):
+        a = np.array(data, dtype=np.uint64)
+        shape = a.shape
+        a = np.ascontiguousarray(a.reshape(-1, shape[-1]))
+        rc = self.L.ms_ntt(self.h, a.ctypes.data_as(_u64p), C.c_size_t(a.shape[1]), C.c_size_t(a.shape[0]), C.c_int(1 if inverse else 0))
+        return rc, a.reshape(shape)
+
+    def coset_lde(self, coeffs, shift, L):
+        c = np.ascontiguousarray(np.atleast_2d(np.asarray(coeffs, dtype=np.uint64)))
+        out = np.zeros((c.shape[0], L), dtype=np.uint64)
+        rc = self.L.ms_coset_lde(self.h, c.ctypes.data_as(_u64p), C.c_size_t(c.shape[1]), C.c_size_t(c.shape[0]), C.c_uint64(shift),
+                                 out.ctypes.data_as(_u64p), C.c_size_t(L))
+        return rc, out

@@ -1,0 +1,151 @@
+// field.hpp — Goldilocks / BabyBear base fields and their extension towers
+// (reference: src/field.rs:36-109).  Canonical representatives everywhere:
+// every value handed between kernels is < P, so results are bit-identical to
+// arkworks' `into_bigint()` of the same field element.
+//
+//   Goldilocks  p = 2^64 - 2^32 + 1, generator 7           (field.rs:43-47)
+//               Fp2 = Fp[u]/(u^2 - 7)                       (field.rs:50-62)
+//   BabyBear    p = 2013265921, "generator" 440564289       (field.rs:72-76, quirk Q8)
+//               Fp2 = Fp[u]/(u^2 - 11)                      (field.rs:78-91)
+//               Fp4 = Fp2[v]/(v^2 - (2013265910 + u))       (field.rs:93-109)
+#pragma once
+#include "rt.hpp"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+struct GL {
+  typedef u64 T;
+  static constexpr int ID = 0;
+  static constexpr u64 P = 0xFFFFFFFF00000001ULL;
+  static constexpr u64 EPS = 0xFFFFFFFFULL;  // 2^64 mod p
+  static constexpr u64 GENERATOR = 7;
+  static constexpr int TWO_ADICITY = 32;
+  static constexpr int EXT = 2;  // StarkField::Extension = GoldilocksFp2 (field.rs:38-41)
+  static constexpr u64 NR2 = 7;
+  static constexpr int MAX_DIGITS = 20;
+  static MS_HD T add(T a, T b) {
+    T s = a + b;
+    if (s < a) s += EPS;         // wrapped: + 2^64 == + EPS (mod p); result < p
+    else if (s >= P) s -= P;
+    return s;
+  }
+  static MS_HD T sub(T a, T b) {
+    T d = a - b;
+    if (a < b) d -= EPS;         // wrapped: - 2^64 == - EPS (mod p)
+    return d;
+  }
+  static MS_HD T neg(T a) { return a ? P - a : 0; }
+  // 128-bit product folded with 2^64 == 2^32 - 1 and 2^96 == -1 (mod p)
+  static MS_HD T reduce128(u64 lo, u64 hi) {
+    u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
+    u64 t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= EPS;
+    u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * EPS
+    u64 r = t0 + t1;
+    if (r < t1) r += EPS;
+    if (r >= P) r -= P;
+    return r;
+  }
+  static MS_HD T mul(T a, T b) { return reduce128(a * b, ms_mulhi64(a, b)); }
+  static MS_HD T from_u64(u64 v) { return v; }
+  static MS_HD u64 to_u64(T v) { return v; }
+};
+
+struct BB {
+  typedef u32 T;
+  static constexpr int ID = 1;
+  static constexpr u64 P = 2013265921ULL;
+  static constexpr u64 GENERATOR = 440564289ULL;
+  static constexpr int TWO_ADICITY = 27;
+  static constexpr int EXT = 4;  // StarkField::Extension = BabyBearFp4 (field.rs:67-70)
+  static constexpr u64 NR2 = 11;
+  static constexpr int MAX_DIGITS = 10;
+  static MS_HD T add(T a, T b) { u32 s = a + b; if (s >= (u32)P) s -= (u32)P; return s; }
+  static MS_HD T sub(T a, T b) { return a >= b ? a - b : a + (u32)P - b; }
+  static MS_HD T neg(T a) { return a ? (u32)P - a : 0; }
+  static MS_HD T mul(T a, T b) { return (T)(((u64)a * (u64)b) % P); }
+  static MS_HD T from_u64(u64 v) { return (T)v; }
+  static MS_HD u64 to_u64(T v) { return v; }
+};
+
+template <class F> MS_HD typename F::T f_pow(typename F::T a, u64 e) {
+  typename F::T r = F::from_u64(1);
+  while (e) { if (e & 1) r = F::mul(r, a); a = F::mul(a, a); e >>= 1; }
+  return r;
+}
+template <class F> MS_HD typename F::T f_inv(typename F::T a) { return f_pow<F>(a, F::P - 2); }
+
+// [ark-mem] Radix2EvaluationDomain::new(n).group_gen: GENERATOR^((p-1)/2^s) squared (s - log2 n) times
+template <class F> inline typename F::T f_root_of_unity(int log_n) {
+  typename F::T w = f_pow<F>(F::from_u64(F::GENERATOR), (F::P - 1) >> F::TWO_ADICITY);
+  for (int i = log_n; i < F::TWO_ADICITY; i++) w = F::mul(w, w);
+  return w;
+}
+
+// ---------------------------------------------------------------------------
+// Extension elements: E base limbs in registers.  E == 1 is the base field.
+// ---------------------------------------------------------------------------
+template <class F, int E> struct Ext { typename F::T c[E]; };
+
+template <class F, int E> MS_HD Ext<F, E> e_zero() { Ext<F, E> r; for (int i = 0; i < E; i++) r.c[i] = 0; return r; }
+template <class F, int E> MS_HD Ext<F, E> e_from_base(typename F::T b) { Ext<F, E> r = e_zero<F, E>(); r.c[0] = b; return r; }
+template <class F, int E> MS_HD Ext<F, E> e_one() { return e_from_base<F, E>(F::from_u64(1)); }
+template <class F, int E> MS_HD Ext<F, E> e_add(const Ext<F, E>& a, const Ext<F, E>& b) { Ext<F, E> r; for (int i = 0; i < E; i++) r.c[i] = F::add(a.c[i], b.c[i]); return r; }
+template <class F, int E> MS_HD Ext<F, E> e_sub(const Ext<F, E>& a, const Ext<F, E>& b) { Ext<F, E> r; for (int i = 0; i < E; i++) r.c[i] = F::sub(a.c[i], b.c[i]); return r; }
+template <class F, int E> MS_HD Ext<F, E> e_mul_base(const Ext<F, E>& a, typename F::T b) { Ext<F, E> r; for (int i = 0; i < E; i++) r.c[i] = F::mul(a.c[i], b); return r; }
+template <class F, int E> MS_HD bool e_is_zero(const Ext<F, E>& a) { bool z = true; for (int i = 0; i < E; i++) z = z && (a.c[i] == 0); return z; }
+template <class F, int E> MS_HD bool e_eq(const Ext<F, E>& a, const Ext<F, E>& b) { bool z = true; for (int i = 0; i < E; i++) z = z && (a.c[i] == b.c[i]); return z; }
+
+template <class F> MS_HD Ext<F, 1> e_mul(const Ext<F, 1>& a, const Ext<F, 1>& b) { Ext<F, 1> r; r.c[0] = F::mul(a.c[0], b.c[0]); return r; }
+template <class F> MS_HD Ext<F, 2> e_mul(const Ext<F, 2>& a, const Ext<F, 2>& b) {
+  // Karatsuba: 3 base multiplications + one by the small non-residue
+  typename F::T v0 = F::mul(a.c[0], b.c[0]);
+  typename F::T v1 = F::mul(a.c[1], b.c[1]);
+  typename F::T s = F::mul(F::add(a.c[0], a.c[1]), F::add(b.c[0], b.c[1]));
+  Ext<F, 2> r;
+  r.c[0] = F::add(v0, F::mul(F::from_u64(F::NR2), v1));
+  r.c[1] = F::sub(F::sub(s, v0), v1);
+  return r;
+}
+// multiply an Fp2 element by the quartic non-residue (2013265910 + u) = (u - 11) (BabyBear)
+template <class F> MS_HD Ext<F, 2> e_mul_nr4(const Ext<F, 2>& a) {
+  // (a0 + a1 u)(n0 + u) = (a0 n0 + NR2 a1) + (a0 + a1 n0) u ,  n0 = 2013265910 = -11 mod p
+  typename F::T n0 = F::from_u64(2013265910ULL % F::P);
+  Ext<F, 2> r;
+  r.c[0] = F::add(F::mul(a.c[0], n0), F::mul(F::from_u64(F::NR2), a.c[1]));
+  r.c[1] = F::add(a.c[0], F::mul(a.c[1], n0));
+  return r;
+}
+template <class F> MS_HD Ext<F, 4> e_mul(const Ext<F, 4>& a, const Ext<F, 4>& b) {
+  Ext<F, 2> a0{{a.c[0], a.c[1]}}, a1{{a.c[2], a.c[3]}}, b0{{b.c[0], b.c[1]}}, b1{{b.c[2], b.c[3]}};
+  Ext<F, 2> v0 = e_mul<F>(a0, b0), v1 = e_mul<F>(a1, b1);
+  Ext<F, 2> s = e_mul<F>(e_add<F, 2>(a0, a1), e_add<F, 2>(b0, b1));
+  Ext<F, 2> r0 = e_add<F, 2>(v0, e_mul_nr4<F>(v1));
+  Ext<F, 2> r1 = e_sub<F, 2>(e_sub<F, 2>(s, v0), v1);
+  Ext<F, 4> r; r.c[0] = r0.c[0]; r.c[1] = r0.c[1]; r.c[2] = r1.c[0]; r.c[3] = r1.c[1];
+  return r;
+}
+template <class F, int E> MS_HD Ext<F, E> e_pow(Ext<F, E> a, u64 e) {
+  Ext<F, E> r = e_one<F, E>();
+  while (e) { if (e & 1) r = e_mul<F>(r, a); a = e_mul<F>(a, a); e >>= 1; }
+  return r;
+}
+
+// host-side inverses (only used for small per-call scalars)
+template <class F> inline Ext<F, 1> e_inv(const Ext<F, 1>& a) { Ext<F, 1> r; r.c[0] = f_inv<F>(a.c[0]); return r; }
+template <class F> inline Ext<F, 2> e_inv(const Ext<F, 2>& a) {
+  typename F::T n = F::sub(F::mul(a.c[0], a.c[0]), F::mul(F::from_u64(F::NR2), F::mul(a.c[1], a.c[1])));
+  typename F::T ni = f_inv<F>(n);
+  Ext<F, 2> r; r.c[0] = F::mul(a.c[0], ni); r.c[1] = F::mul(F::neg(a.c[1]), ni);
+  return r;
+}
+
+// SoA view of a vector of extension elements: limb k of element j at p[k*limb_stride + off + j*stride]
+template <class F, int E> struct ExtView {
+  typename F::T* p;
+  size_t limb_stride;
+  MS_HD Ext<F, E> load(size_t j) const { Ext<F, E> r; for (int k = 0; k < E; k++) r.c[k] = p[k * limb_stride + j]; return r; }
+  MS_HD void store(size_t j, const Ext<F, E>& v) const { for (int k = 0; k < E; k++) p[k * limb_stride + j] = v.c[k]; }
+};

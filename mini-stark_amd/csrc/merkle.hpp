@@ -1,0 +1,259 @@
+// merkle.hpp — SHA-256 Merkle commitment kernels.
+//
+// Replaces MerkleTree::new (src/merkle.rs:81-148):
+//   leaf pass  : one digest per group of `leafs_per_node` field elements,
+//                D(to_string(x0) || to_string(x1) || ...)         (merkle.rs:124-128,162-168)
+//   inner pass : D(child_0 || ... || child_{ic-1}), level by level, nodes
+//                appended level-major, root last                   (merkle.rs:131-140,171-177)
+// [ark-mem] `to_string` is arkworks' Display: canonical decimal for Fp (ZERO
+// prints as the empty string when zero_as_empty=1), and
+// "QuadExtField(c0 + c1 * u)" (nested) for the extension towers.
+//
+// One thread owns one digest.  The message is produced as a byte stream
+// (decimal conversion in registers) into a 16-word block buffer that lives in
+// LDS word-interleaved across the workgroup (bank-conflict free), and is
+// compressed every 64 bytes; SHA-256 state and message schedule stay in
+// registers.  Both passes are 32-bit-ALU bound, not HBM bound: algorithmic
+// traffic is lpn*E*sizeof(T) + 32 bytes per leaf group and 96 bytes per inner
+// node against ~2-3 compressions each.
+#pragma once
+#include "field.hpp"
+
+namespace msmerkle {
+
+constexpr int THREADS = 256;
+
+MS_HD u32 rotr32(u32 x, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(x, x, n);
+#else
+  return (x >> n) | (x << (32 - n));
+#endif
+}
+MS_HD u32 bswap32(u32 x) { return __builtin_bswap32(x); }
+
+struct Sha256 {
+  u32 st[8];
+  MS_HD void init() {
+    st[0] = 0x6a09e667; st[1] = 0xbb67ae85; st[2] = 0x3c6ef372; st[3] = 0xa54ff53a;
+    st[4] = 0x510e527f; st[5] = 0x9b05688c; st[6] = 0x1f83d9ab; st[7] = 0x5be0cd19;
+  }
+  // one compression of the 16 big-endian words w[0..15] (clobbers w)
+  MS_HD void compress(u32 (&w)[16]) {
+    constexpr u32 K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      if (i >= 16) {
+        u32 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+        u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+        u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+        w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+      }
+      u32 S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+      u32 ch = g ^ (e & (f ^ g));
+      u32 t1 = h + S1 + ch + K[i] + w[i & 15];
+      u32 S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+      u32 mj = (a & b) | (c & (a | b));
+      u32 t2 = S0 + mj;
+      h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+  }
+};
+
+// byte stream -> SHA-256, block buffer in LDS (word i of thread t at blk[i*nthreads + t])
+struct ShaStream {
+  Sha256 h;
+  u32* blk; int nthreads, tid;
+  u32 cur;      // bytes of the word being assembled (big-endian)
+  u32 nb;       // bytes in the current block
+  u64 total;
+  MS_HD void init(u32* lds_words, int nthreads_, int tid_) { h.init(); blk = lds_words; nthreads = nthreads_; tid = tid_; cur = 0; nb = 0; total = 0; }
+  MS_HD void flush_block() {
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = blk[i * nthreads + tid];
+    h.compress(w);
+    nb = 0;
+  }
+  MS_HD void put(u32 ch) {
+    cur = (cur << 8) | ch;
+    nb++; total++;
+    if ((nb & 3) == 0) {
+      blk[((nb >> 2) - 1) * nthreads + tid] = cur;
+      cur = 0;
+      if (nb == 64) flush_block();
+    }
+  }
+  MS_HD void finish(u32 (&out)[8]) {
+    u64 bits = total * 8;
+    put(0x80);
+    while (nb != 56) put(0);
+    for (int k = 7; k >= 0; k--) put((u32)(bits >> (8 * k)) & 0xff);
+    for (int k = 0; k < 8; k++) out[k] = h.st[k];
+    total = 0;
+  }
+};
+
+// canonical decimal of a base element, most significant digit first, no
+// leading zeros; ZERO -> "" (zero_as_empty) or "0".
+template <class F> MS_HD void put_dec(ShaStream& s, typename F::T v_, int zero_as_empty) {
+  u64 v = F::to_u64(v_);
+  if (v == 0) { if (!zero_as_empty) s.put('0'); return; }
+  constexpr int ND = F::MAX_DIGITS;  // 20 (Goldilocks) / 10 (BabyBear)
+  u32 chunk[ND / 5];                 // 5-digit chunks, most significant first
+  if (ND == 20) {
+    u64 hi = v / 10000000000ULL, lo = v - hi * 10000000000ULL;  // hi < 1.85e9, lo < 1e10
+    u32 hi32 = (u32)hi;
+    u32 lo_hi = (u32)(lo / 100000ULL), lo_lo = (u32)(lo - (u64)lo_hi * 100000ULL);
+    chunk[0] = hi32 / 100000u; chunk[1] = hi32 - chunk[0] * 100000u;
+    chunk[ND / 5 - 2] = lo_hi; chunk[ND / 5 - 1] = lo_lo;
+  } else {
+    u32 x = (u32)v;
+    chunk[0] = x / 100000u; chunk[1] = x - chunk[0] * 100000u;
+  }
+  bool started = false;
+#pragma unroll
+  for (int c = 0; c < ND / 5; c++) {
+    u32 x = chunk[c];
+    u32 d4 = x / 10000u; x -= d4 * 10000u;
+    u32 d3 = x / 1000u; x -= d3 * 1000u;
+    u32 d2 = x / 100u; x -= d2 * 100u;
+    u32 d1 = x / 10u; u32 d0 = x - d1 * 10u;
+    started = started || d4; if (started) s.put('0' + d4);
+    started = started || d3; if (started) s.put('0' + d3);
+    started = started || d2; if (started) s.put('0' + d2);
+    started = started || d1; if (started) s.put('0' + d1);
+    started = started || d0; if (started) s.put('0' + d0);
+  }
+}
+template <class F, int E> struct Display {
+  static MS_HD void put(ShaStream& s, const typename F::T* c, int zae) {
+    const char* a = "QuadExtField(";
+    for (int i = 0; i < 13; i++) s.put((u32)a[i]);
+    Display<F, E / 2>::put(s, c, zae);
+    s.put(' '); s.put('+'); s.put(' ');
+    Display<F, E / 2>::put(s, c + E / 2, zae);
+    s.put(' '); s.put('*'); s.put(' '); s.put('u'); s.put(')');
+  }
+};
+template <class F> struct Display<F, 1> {
+  static MS_HD void put(ShaStream& s, const typename F::T* c, int zae) { put_dec<F>(s, c[0], zae); }
+};
+
+// Leaf-group hashing.  Element f of the committed vector lives at
+//   base + (f % width) * col_stride + (f / width) * row_stride + limb * limb_stride
+// (row-major trace: width=1,row_stride=1; column-major LDE: width=c,col_stride=L;
+//  FRI codeword: width=1, limb_stride=D).
+template <class F, int E> struct LeafHashKernel {
+  typedef typename F::T T;
+  static constexpr int THREADS = msmerkle::THREADS;
+  struct Params {
+    const T* base; size_t col_stride, row_stride, limb_stride;
+    u32 width, lpn; int zero_as_empty;
+    size_t ngroups;
+    u32* nodes;  // 8 words per digest, standard byte order in memory
+  };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_HD size_t lds_bytes() { return (size_t)16 * THREADS * sizeof(u32); }
+  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char* lds) {
+    const size_t g = (size_t)bx * nthreads + tid;
+    if (g >= p.ngroups) return;
+    ShaStream s; s.init(reinterpret_cast<u32*>(lds), nthreads, tid);
+    size_t f = g * p.lpn;
+    size_t row = f / p.width; u32 col = (u32)(f - row * p.width);
+    for (u32 i = 0; i < p.lpn; i++) {
+      T c[E];
+      const T* ptr = p.base + (size_t)col * p.col_stride + row * p.row_stride;
+#pragma unroll
+      for (int k = 0; k < E; k++) c[k] = ptr[(size_t)k * p.limb_stride];
+      Display<F, E>::put(s, c, p.zero_as_empty);
+      if (++col == p.width) { col = 0; row++; }
+    }
+    u32 d[8]; s.finish(d);
+    u32* out = p.nodes + g * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k] = bswap32(d[k]);
+  }
+};
+
+// Inner levels.  `nlevels` consecutive levels are processed by the launch: with
+// nlevels > 1 the grid must be a single workgroup (fused tree top).
+struct InnerHashKernel {
+  static constexpr int THREADS = msmerkle::THREADS;
+  struct Params { u32* nodes; size_t child_off, nchildren; u32 ic; u32 nlevels; };
+  static MS_HD int nphases(const Params& p) { return (int)p.nlevels; }
+  static MS_DEV void phase(int ph, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
+    size_t child_off = p.child_off, nchildren = p.nchildren;
+    for (int l = 0; l < ph; l++) { child_off += nchildren; nchildren /= p.ic; }
+    const size_t nparents = nchildren / p.ic;
+    const size_t stride = (p.nlevels > 1) ? (size_t)nthreads : 0;
+    for (size_t g = (size_t)bx * nthreads + tid; g < nparents; g += stride) {
+      const u32* ch = p.nodes + (child_off + g * p.ic) * 8;
+      Sha256 h; h.init();
+      u32 w[16];
+      for (u32 b = 0; b < p.ic / 2; b++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = bswap32(ch[b * 16 + i]);
+        h.compress(w);
+      }
+      w[0] = 0x80000000u;
+#pragma unroll
+      for (int i = 1; i < 15; i++) w[i] = 0;
+      w[15] = p.ic * 256u;  // message bits (ic * 32 bytes)
+      h.compress(w);
+      u32* out = p.nodes + (child_off + nchildren + g) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; k++) out[k] = bswap32(h.st[k]);
+      if (stride == 0) break;
+    }
+  }
+};
+
+// MerklePath extraction (src/merkle.rs:216-288) for `ntargets` leaf indices held
+// on the device.  Writes, per target, the serialised path
+//   u64 leaf_index | lpn*E u64 limbs | u64 nlevels | nlevels * ic * 32 bytes
+// at out + t*path_bytes.
+template <class F, int E> struct PathKernel {
+  typedef typename F::T T;
+  static constexpr int THREADS = 64;
+  struct Params {
+    const T* leafs; size_t limb_stride;   // FRI codeword view (width = 1)
+    const u32* nodes; size_t leaf_num; u32 lpn, ic, nlevels /* levels-1 */;
+    const unsigned long long* idx; u32 ntargets;
+    unsigned char* out; const size_t* out_off;  // byte offset per target
+  };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
+    const u32 t = (u32)bx * nthreads + tid;
+    if (t >= p.ntargets) return;
+    u64* o = reinterpret_cast<u64*>(p.out + p.out_off[t]);
+    const size_t li = (size_t)p.idx[t];
+    if (li >= p.leaf_num) return;  // value not found: the host reports MS_ERR_LEAF_NOT_FOUND
+    *o++ = li;
+    const size_t start = li - li % p.lpn;  // merkle.rs:230-236
+    for (u32 i = 0; i < p.lpn; i++)
+      for (int k = 0; k < E; k++) *o++ = F::to_u64(p.leafs[(size_t)k * p.limb_stride + start + i]);
+    *o++ = p.nlevels;
+    u32* o32 = reinterpret_cast<u32*>(o);
+    size_t cur = li / p.lpn;       // index inside the current level
+    size_t level_off = 0, level_n = p.leaf_num / p.lpn;
+    for (u32 l = 0; l < p.nlevels; l++) {  // merkle.rs:241-265
+      const size_t s = cur - cur % p.ic;
+      const u32* src = p.nodes + (level_off + s) * 8;
+      for (u32 i = 0; i < p.ic * 8; i++) *o32++ = src[i];
+      level_off += level_n; level_n /= p.ic; cur /= p.ic;
+    }
+  }
+};
+
+}  // namespace msmerkle

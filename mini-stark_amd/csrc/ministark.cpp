@@ -1,0 +1,906 @@
+// ministark.cpp — host side of the C ABI (include/ministark.h): context, NTT
+// plans, Merkle builder and the Stark::prove / Fri::prove stage functions that
+// sequence the kernels of ntt.hpp / merkle.hpp / poly.hpp on one HIP stream.
+// Compiled with hipcc for gfx950 (libministark.so).  There is no CPU fallback.
+#include "../../include/ministark.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "field.hpp"
+#include "merkle.hpp"
+#include "ntt.hpp"
+#include "poly.hpp"
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) msrt::free_dev(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    if (msrt::malloc_dev(&p, want)) { p = nullptr; return 1; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) msrt::free_dev(p); p = nullptr; cap = 0; }
+  template <class U> U* as() const { return reinterpret_cast<U*>(p); }
+};
+
+// ---- src/util.rs:4-44 ------------------------------------------------------
+inline bool is_pow2(u64 n) { return (n & (n - 1)) == 0; }
+inline int ctz64(u64 x) { return x ? __builtin_ctzll(x) : 64; }
+inline long log_two_k(u64 number, u64 base) {
+  int log_n = ctz64(base);
+  if (!is_pow2(number)) return -1;
+  int p2 = ctz64(number);
+  if (p2 % log_n != 0) return -2;
+  return p2 / log_n;
+}
+inline u64 ceil_log2_k(u64 number, u64 base) {
+  if (number == 1) return 1;
+  u64 lb = ctz64(base), ln = ctz64(number);
+  if (is_pow2(number) && ln % lb == 0) return ln;
+  u64 np2 = 64 - __builtin_clzll(number);
+  return ((np2 + lb - 1) / lb) * lb;
+}
+
+struct CtxBase {
+  std::string err;
+  virtual ~CtxBase() {}
+  virtual int ext_degree() const = 0;
+  virtual int set_stream(void* s) = 0;
+  virtual int synchronize() = 0;
+  virtual int trace_commit(const u64* trace, bool on_device, size_t N, size_t w, size_t lpn, u8* root) = 0;
+  virtual int interpolate() = 0;
+  virtual int polys_lincomb(const u64* s, const int* idx, int k) = 0;
+  virtual int polys_append(const u64* coeffs, size_t n) = 0;
+  virtual int polys_count() const = 0;
+  virtual int poly_read(int i, u64* out) = 0;
+  virtual int lde_commit(size_t blowup, u64 shift, size_t lpn, u8* root) = 0;
+  virtual int lde_read(u64* out) = 0;
+  virtual int mix(u64 r) = 0;
+  virtual int validity_read(u64* out) = 0;
+  virtual int eval_ext(const u64* z, int q, u64* out) = 0;
+  virtual int fri_begin(size_t blowup, size_t rounds, u8* root0) = 0;
+  virtual int fri_deep(const u64* z, u64* B) = 0;
+  virtual int fri_fold_commit(const u64* alpha, u8* root) = 0;
+  virtual int fri_round_info(int r, u64* ncoef, u64* D) = 0;
+  virtual int fri_round_poly_read(int r, u64* out) = 0;
+  virtual int fri_round_codeword_read(int r, u64* out) = 0;
+  virtual int fri_query(const u64* betas, int nq) = 0;
+  virtual size_t fri_proof_size() const = 0;
+  virtual int fri_proof_read(u8* out) = 0;
+  virtual int merkle_commit(const u64* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, u8* nodes_out, size_t cap, size_t* nn, u8* root) = 0;
+  virtual int ntt(u64* data, size_t n, size_t batch, int inverse) = 0;
+  virtual int coset_lde(const u64* coeffs, size_t ncoef, size_t batch, u64 shift, u64* out, size_t L) = 0;
+  virtual int bench_lde(size_t blowup, u64 shift) = 0;
+};
+
+#define CK(...) do { int _e = (__VA_ARGS__); if (_e) return this->fail_rt(_e, #__VA_ARGS__); } while (0)
+#define RQ(...) do { int _e = (__VA_ARGS__); if (_e) return _e; } while (0)
+
+template <class F> struct Ctx : CtxBase {
+  typedef typename F::T T;
+  static constexpr int E = F::EXT;
+  typedef Ext<F, E> XE;
+
+  int device = 0, zae = 1;
+  msrt::Stream* own_stream = nullptr;
+  msrt::Stream* stream = nullptr;
+  void* pinned = nullptr; size_t pinned_cap = 0;
+
+  int fail_rt(int e, const char* what) { err = std::string("runtime error ") + std::to_string(e) + " in " + what + ": " + msrt::last_error_string(); return MS_ERR_HIP; }
+  int fail(int code, const char* msg) { err = msg; return code; }
+
+  // ------------------------------------------------------------------ NTT plans
+  struct Plan {
+    int log_n = 0, npass = 0, K[4] = {0, 0, 0, 0}, lo_bits = 0;
+    DevBuf tw_lo, tw_hi, w_r[4];
+    T n_inv = 0;
+  };
+  std::map<int, Plan*> plans;  // key = log_n*2 + inverse
+  DevBuf ntt_scratch;
+
+  int get_plan(int log_n, bool inverse, Plan** out) {
+    int key = log_n * 2 + (inverse ? 1 : 0);
+    auto it = plans.find(key);
+    if (it != plans.end()) { *out = it->second; return 0; }
+    if (log_n > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "domain larger than the field's two-adicity");
+    Plan* pl = new Plan();
+    pl->log_n = log_n;
+    if (log_n <= msntt::MAX_LOG_R) { pl->npass = 1; pl->K[0] = log_n; }
+    else {
+      int P = (log_n + 8) / 9;
+      pl->npass = P;
+      for (int i = 0; i < P; i++) pl->K[i] = log_n / P + (i < log_n % P ? 1 : 0);
+    }
+    T w = f_root_of_unity<F>(log_n);
+    if (inverse) w = f_inv<F>(w);
+    const size_t n = (size_t)1 << log_n;
+    pl->n_inv = f_inv<F>(F::from_u64(n % F::P));
+    pl->lo_bits = (log_n + 1) / 2;
+    const size_t nlo = (size_t)1 << pl->lo_bits, nhi = (size_t)1 << (log_n - pl->lo_bits);
+    std::vector<T> lo(nlo), hi(nhi);
+    T x = F::from_u64(1);
+    for (size_t j = 0; j < nlo; j++) { lo[j] = x; x = F::mul(x, w); }
+    T wh = x;  // w^nlo
+    x = F::from_u64(1);
+    for (size_t j = 0; j < nhi; j++) { hi[j] = x; x = F::mul(x, wh); }
+    if (pl->tw_lo.ensure(nlo * sizeof(T)) || pl->tw_hi.ensure(nhi * sizeof(T))) { delete pl; return fail(MS_ERR_NOMEM, "twiddle tables"); }
+    CK(msrt::h2d(pl->tw_lo.p, lo.data(), nlo * sizeof(T), stream));
+    CK(msrt::h2d(pl->tw_hi.p, hi.data(), nhi * sizeof(T), stream));
+    CK(msrt::sync(stream));
+    for (int i = 0; i < pl->npass; i++) {
+      const size_t r = (size_t)1 << pl->K[i];
+      T wr = f_root_of_unity<F>(pl->K[i]);
+      if (inverse) wr = f_inv<F>(wr);
+      std::vector<T> tab(r);
+      x = F::from_u64(1);
+      for (size_t j = 0; j < r; j++) { tab[j] = x; x = F::mul(x, wr); }
+      if (pl->w_r[i].ensure(r * sizeof(T))) { delete pl; return fail(MS_ERR_NOMEM, "w_r table"); }
+      CK(msrt::h2d(pl->w_r[i].p, tab.data(), r * sizeof(T), stream));
+      CK(msrt::sync(stream));
+    }
+    plans[key] = pl;
+    *out = pl;
+    return 0;
+  }
+
+  // batch transforms of size 2^log_n: src (n_in valid elements per entry, zero padded) -> dst
+  int ntt_run(int log_n, bool inverse, const T* src, size_t src_bstride, size_t n_in, T* dst, size_t dst_bstride, size_t batch) {
+    if (batch == 0) return 0;
+    const size_t n = (size_t)1 << log_n;
+    if (log_n == 0) {  // size-1 transform: identity
+      for (size_t b = 0; b < batch; b++) {
+        if (n_in >= 1) { if (src + b * src_bstride != dst + b * dst_bstride) CK(msrt::d2d(dst + b * dst_bstride, src + b * src_bstride, sizeof(T), stream)); }
+        else CK(msrt::memset_dev(dst + b * dst_bstride, 0, sizeof(T), stream));
+      }
+      return 0;
+    }
+    Plan* pl;
+    RQ(get_plan(log_n, inverse, &pl));
+    const int P = pl->npass;
+    const bool aliased = ((const void*)src == (const void*)dst);
+    T* scr = nullptr;
+    const bool last_inplace = P >= 2 && !(aliased && P % 2 == 0);
+    const bool need_scr = P >= 3 || (P == 2 && !last_inplace);
+    if (need_scr) {
+      if (ntt_scratch.ensure(batch * n * sizeof(T))) return fail(MS_ERR_NOMEM, "ntt scratch");
+      scr = ntt_scratch.as<T>();
+    }
+    const T* in = src; size_t in_bs = src_bstride;
+    int log_Rp = 0;
+    for (int k = 0; k < P; k++) {
+      T* out; size_t out_bs;
+      if (k == P - 1) { out = dst; out_bs = dst_bstride; }
+      else {
+        const bool even = ((P - 1 - (k + 1)) % 2 == 0);
+        const bool to_dst = last_inplace ? even : !even;
+        out = to_dst ? dst : scr; out_bs = to_dst ? dst_bstride : n;
+      }
+      msntt::PassParams<F> pp;
+      pp.src = in; pp.dst = out; pp.src_bstride = in_bs; pp.dst_bstride = out_bs;
+      pp.n_in = (k == 0) ? n_in : n;
+      pp.tw_lo = pl->tw_lo.template as<T>(); pp.tw_hi = pl->tw_hi.template as<T>(); pp.w_r = pl->w_r[k].template as<T>();
+      pp.scale = (inverse && k == P - 1) ? pl->n_inv : F::from_u64(1);
+      pp.log_n = log_n; pp.log_r = pl->K[k]; pp.log_Rp = log_Rp; pp.lo_bits = pl->lo_bits;
+      const int cols_log = log_n - pl->K[k];
+      pp.log_C = cols_log < msntt::TILE_LOG_C ? cols_log : msntt::TILE_LOG_C;
+      pp.first = (k == 0); pp.last = (k == P - 1);
+      const size_t tiles = ((size_t)1 << cols_log) >> pp.log_C;
+      const size_t lds = msntt::PassKernel<F>::lds_bytes(pp.log_r, pp.log_C);
+      CK(msrt::launch<msntt::PassKernel<F>>(stream, (unsigned)tiles, (unsigned)batch, msntt::THREADS, lds, pp));
+      in = out; in_bs = out_bs;
+      log_Rp += pl->K[k];
+    }
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ Merkle
+  struct TreeShape { size_t leaf_num = 0, lpn = 0, ic = 0, levels = 0, nodes = 0; };
+  // src/merkle.rs:89-118 (shape checks and node count)
+  int tree_shape(size_t leaf_num, size_t lpn, size_t ic, TreeShape* ts) {
+    if (lpn == 0 || ic < 2 || !is_pow2(ic)) return fail(MS_ERR_SHAPE, "merkle: bad leafs_per_node / inner_children");
+    const size_t node_num = leaf_num / lpn;
+    long lg = log_two_k(node_num, ic);
+    if (lg < 0) return fail(MS_ERR_SHAPE, lg == -1 ? "number if not a power of 2" : "number if not a power of base");
+    if (leaf_num % lpn != 0) return fail(MS_ERR_SHAPE, "merkle: leaf_num % leafs_per_node != 0");
+    if (lg >= 64 || node_num == 0) return fail(MS_ERR_SHAPE, "Tree is not full!");
+    ts->leaf_num = leaf_num; ts->lpn = lpn; ts->ic = ic; ts->levels = (size_t)lg + 1;
+    size_t total = 0, m = node_num;
+    for (;;) { total += m; if (m == 1) break; m /= ic; }
+    ts->nodes = total;
+    return 0;
+  }
+  template <int EL>
+  int tree_build(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, const TreeShape& ts, DevBuf& nodes) {
+    if (nodes.ensure(ts.nodes * 32)) return fail(MS_ERR_NOMEM, "merkle nodes");
+    typename msmerkle::LeafHashKernel<F, EL>::Params lp;
+    lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
+    lp.width = width; lp.lpn = (u32)ts.lpn; lp.zero_as_empty = zae; lp.ngroups = ts.leaf_num / ts.lpn; lp.nodes = nodes.as<u32>();
+    const size_t blocks = (lp.ngroups + msmerkle::THREADS - 1) / msmerkle::THREADS;
+    CK(msrt::launch<msmerkle::LeafHashKernel<F, EL>>(stream, (unsigned)blocks, 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
+    size_t child_off = 0, nchildren = lp.ngroups;
+    while (nchildren > 1) {
+      msmerkle::InnerHashKernel::Params ip;
+      ip.nodes = nodes.as<u32>(); ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ts.ic;
+      const size_t nparents = nchildren / ts.ic;
+      if (nparents <= 4 * (size_t)msmerkle::THREADS) {  // fused tree top: one workgroup walks the remaining levels
+        u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ts.ic) nl++;
+        ip.nlevels = nl;
+        CK(msrt::launch<msmerkle::InnerHashKernel>(stream, 1, 1, msmerkle::THREADS, 0, ip));
+        break;
+      }
+      ip.nlevels = 1;
+      CK(msrt::launch<msmerkle::InnerHashKernel>(stream, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
+      child_off += nchildren; nchildren = nparents;
+    }
+    return 0;
+  }
+  int read_root(const DevBuf& nodes, const TreeShape& ts, u8* root) {
+    CK(msrt::d2h(pinned, nodes.as<u8>() + (ts.nodes - 1) * 32, 32, stream));
+    CK(msrt::sync(stream));
+    memcpy(root, pinned, 32);
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ session state
+  size_t N = 0, w = 0, L = 0, blowup = 0;
+  int npolys = 0; size_t polys_cap = 0;
+  bool have_trace = false, have_polys = false, have_lde = false, have_validity = false;
+  DevBuf d_trace, d_polys, d_coef, d_lde, d_trace_nodes, d_lde_nodes, d_io, d_partials, d_small;
+  TreeShape trace_ts, lde_ts;
+  size_t lde_c = 0;
+
+  struct Round { DevBuf poly, cw, nodes; size_t cap = 0, ncoef = 0, D = 0; TreeShape ts; };
+  std::vector<Round*> rounds; size_t nrounds_done = 0, fri_rounds = 0, fri_blowup = 0;
+  bool have_deep = false; XE cur_z; XE cur_B[2];
+  DevBuf d_folded, d_sh, d_blob, d_tabs, d_targets, d_idx, d_deg;
+  size_t blob_size = 0;
+
+  int ensure_polys(size_t count) {
+    if (count <= polys_cap) return 0;
+    size_t ncap = polys_cap ? polys_cap * 2 : 8;
+    while (ncap < count) ncap *= 2;
+    DevBuf nb;
+    if (nb.ensure(ncap * N * sizeof(T))) return fail(MS_ERR_NOMEM, "polys");
+    if (d_polys.p && npolys > 0) { CK(msrt::d2d(nb.p, d_polys.p, (size_t)npolys * N * sizeof(T), stream)); CK(msrt::sync(stream)); }
+    d_polys.release();
+    d_polys = nb; polys_cap = ncap;
+    return 0;
+  }
+
+  int init(int dev, u32 flags) {
+    device = dev; zae = (flags & MS_FLAG_ZERO_DISPLAY_EMPTY) ? 1 : 0;
+    CK(msrt::set_device(dev));
+    CK(msrt::stream_create(&own_stream));
+    stream = own_stream;
+    pinned_cap = 1 << 16;
+    CK(msrt::malloc_host(&pinned, pinned_cap));
+    if (d_small.ensure(4096)) return fail(MS_ERR_NOMEM, "small");
+    return 0;
+  }
+  ~Ctx() {
+    for (auto& kv : plans) { kv.second->tw_lo.release(); kv.second->tw_hi.release(); for (auto& b : kv.second->w_r) b.release(); delete kv.second; }
+    for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
+    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg};
+    for (DevBuf* b : bufs) b->release();
+    if (pinned) msrt::free_host(pinned);
+    if (own_stream) msrt::stream_destroy(own_stream);
+  }
+  int ext_degree() const override { return E; }
+  int set_stream(void* s) override { stream = s ? reinterpret_cast<msrt::Stream*>(s) : own_stream; return 0; }
+  int synchronize() override { CK(msrt::sync(stream)); return 0; }
+
+  static unsigned grid1(size_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+  // staged copies between the u64 ABI and device storage
+  int upload_narrow(const u64* host, size_t n, T* dst) {
+    if (d_io.ensure(n * 8)) return fail(MS_ERR_NOMEM, "io staging");
+    CK(msrt::h2d(d_io.p, host, n * 8, stream));
+    typename mspoly::NarrowKernel<F>::Params p{d_io.as<u64>(), dst, n};
+    CK(msrt::launch<mspoly::NarrowKernel<F>>(stream, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    return 0;
+  }
+  int download_widen(const T* src, size_t n, size_t limb_stride, u32 e, u64* host) {
+    if (n == 0) return 0;
+    if (d_io.ensure(n * e * 8)) return fail(MS_ERR_NOMEM, "io staging");
+    typename mspoly::WidenKernel<F>::Params p{src, d_io.as<u64>(), n, limb_stride, e};
+    CK(msrt::launch<mspoly::WidenKernel<F>>(stream, grid1(n * e, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    CK(msrt::d2h(host, d_io.p, n * e * 8, stream));
+    CK(msrt::sync(stream));
+    return 0;
+  }
+  static bool canonical(const u64* v, size_t n) { for (size_t i = 0; i < n; i++) if (v[i] >= F::P) return false; return true; }
+
+  // ------------------------------------------------------------------ starks.rs:68-73
+  int trace_commit(const u64* trace, bool on_device, size_t N_, size_t w_, size_t lpn, u8* root) override {
+    if (!trace || !root) return fail(MS_ERR_ARG, "null argument");
+    if (!N_ || !w_ || !is_pow2(N_)) return fail(MS_ERR_SHAPE, "trace length must be a power of two (air.rs:23)");
+    if (ctz64(N_) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "trace domain larger than the field's two-adicity (air.rs:74)");
+    TreeShape ts;
+    RQ(tree_shape(N_ * w_, lpn, 2, &ts));
+    if (!on_device && !canonical(trace, N_ * w_)) return fail(MS_ERR_ARG, "trace element not canonical (>= p)");
+    have_trace = have_polys = have_lde = have_validity = false; npolys = 0; nrounds_done = 0; have_deep = false; blob_size = 0;
+    if (N_ != N) { polys_cap = 0; d_polys.release(); }
+    N = N_; w = w_;
+    const u64* dsrc;
+    if (on_device) dsrc = trace;
+    else {
+      if (d_trace.ensure(N * w * 8)) return fail(MS_ERR_NOMEM, "trace");
+      CK(msrt::h2d(d_trace.p, trace, N * w * 8, stream));
+      dsrc = d_trace.as<u64>();
+    }
+    RQ(ensure_polys(w + 1));
+    typename mspoly::TransposeInKernel<F>::Params tp{dsrc, d_polys.as<T>(), N, w, N};
+    CK(msrt::launch<mspoly::TransposeInKernel<F>>(stream, grid1(N * w, mspoly::THREADS), 1, mspoly::THREADS, 0, tp));
+    // element f of trace.get_data() = column f % w, row f / w of the column-major copy
+    RQ((tree_build<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
+    trace_ts = ts;
+    RQ(read_root(d_trace_nodes, ts, root));
+    have_trace = true;
+    return MS_OK;
+  }
+  // ------------------------------------------------------------------ air.rs:147-160
+  int interpolate() override {
+    if (!have_trace) return fail(MS_ERR_STATE, "interpolate before trace_commit");
+    RQ(ntt_run(ctz64(N), true, d_polys.as<T>(), N, N, d_polys.as<T>(), N, w));
+    npolys = (int)w; have_polys = true; have_lde = have_validity = false;
+    return MS_OK;
+  }
+  int polys_lincomb(const u64* s, const int* idx, int k) override {
+    if (!have_polys) return fail(MS_ERR_STATE, "lincomb before interpolate");
+    if (!s || !idx || k < 1) return fail(MS_ERR_ARG, "bad lincomb arguments");
+    for (int t = 0; t < k; t++) if (idx[t] < 0 || idx[t] >= npolys || s[t] >= F::P) return fail(MS_ERR_ARG, "lincomb index/scalar out of range");
+    RQ(ensure_polys(npolys + 2));
+    T* dst = d_polys.as<T>() + (size_t)npolys * N;
+    for (int t0 = 0; t0 < k; t0 += mspoly::MAX_TERMS - 1) {
+      typename mspoly::LincombKernel<F>::Params p;
+      p.polys = d_polys.as<T>(); p.stride = N; p.n = N; p.dst = dst;
+      int kk = 0;
+      if (t0 > 0) { p.s[kk] = F::from_u64(1); p.idx[kk] = npolys; kk++; }  // accumulate onto the partial result
+      for (int t = t0; t < k && kk < mspoly::MAX_TERMS; t++, kk++) { p.s[kk] = F::from_u64(s[t]); p.idx[kk] = idx[t]; }
+      p.k = kk;
+      CK(msrt::launch<mspoly::LincombKernel<F>>(stream, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    }
+    npolys++; have_lde = have_validity = false;
+    return MS_OK;
+  }
+  int polys_append(const u64* coeffs, size_t n) override {
+    if (!have_polys) return fail(MS_ERR_STATE, "append before interpolate");
+    if (!coeffs || n > N) return fail(MS_ERR_SHAPE, "constraint polynomial has more than N coefficients (starks.rs:118-119 asserts)");
+    if (!canonical(coeffs, n)) return fail(MS_ERR_ARG, "coefficient not canonical");
+    RQ(ensure_polys(npolys + 2));
+    T* dst = d_polys.as<T>() + (size_t)npolys * N;
+    CK(msrt::memset_dev(dst, 0, N * sizeof(T), stream));
+    if (n) RQ(upload_narrow(coeffs, n, dst));
+    npolys++; have_lde = have_validity = false;
+    return MS_OK;
+  }
+  int polys_count() const override { return npolys; }
+  int poly_read(int i, u64* out) override {
+    if (!have_polys || i < 0 || i >= npolys || !out) return fail(MS_ERR_ARG, "poly_read");
+    return download_widen(d_polys.as<T>() + (size_t)i * N, N, 0, 1, out);
+  }
+
+  // ------------------------------------------------------------------ starks.rs:80-95
+  int lde_compute(size_t blowup_, u64 shift) {
+    const size_t c = (size_t)npolys;
+    const size_t L_ = N * blowup_;
+    if (d_coef.ensure(c * N * sizeof(T)) || d_lde.ensure(c * L_ * sizeof(T))) return fail(MS_ERR_NOMEM, "lde");
+    typename msntt::ScalePowKernel<F>::Params sp;
+    sp.src = d_polys.as<T>(); sp.dst = d_coef.as<T>(); sp.src_bstride = N; sp.dst_bstride = N; sp.n = N;
+    sp.s = F::from_u64(shift); sp.s_step = f_pow<F>(sp.s, msntt::ScalePowKernel<F>::THREADS);
+    const int per_block = msntt::ScalePowKernel<F>::THREADS * msntt::ScalePowKernel<F>::ITEMS;
+    CK(msrt::launch<msntt::ScalePowKernel<F>>(stream, grid1(N, per_block), (unsigned)c, msntt::ScalePowKernel<F>::THREADS, 0, sp));
+    RQ(ntt_run(ctz64(L_), false, d_coef.as<T>(), N, N, d_lde.as<T>(), L_, c));
+    return 0;
+  }
+  int lde_commit(size_t blowup_, u64 shift, size_t lpn, u8* root) override {
+    if (!have_polys) return fail(MS_ERR_STATE, "lde_commit before interpolate");
+    if (!root || !blowup_ || !is_pow2(blowup_) || shift == 0 || shift >= F::P) return fail(MS_ERR_ARG, "bad blowup/shift");
+    const size_t L_ = N * blowup_;
+    if (ctz64(L_) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "LDE domain larger than the field's two-adicity (starks.rs:82-83)");
+    const size_t c = (size_t)npolys;
+    TreeShape ts;
+    RQ(tree_shape(L_ * c, lpn, 2, &ts));
+    RQ(lde_compute(blowup_, shift));
+    L = L_; blowup = blowup_; lde_c = c;
+    RQ((tree_build<1>(d_lde.as<T>(), L, 1, 0, (u32)c, ts, d_lde_nodes)));
+    lde_ts = ts;
+    RQ(read_root(d_lde_nodes, ts, root));
+    have_lde = true;
+    return MS_OK;
+  }
+  int bench_lde(size_t blowup_, u64 shift) override {
+    if (!have_polys) return fail(MS_ERR_STATE, "bench_lde before interpolate");
+    return lde_compute(blowup_, shift);
+  }
+  int lde_read(u64* out) override {
+    if (!have_lde || !out) return fail(MS_ERR_STATE, "lde_read");
+    const size_t tot = L * lde_c;
+    if (d_io.ensure(tot * 8)) return fail(MS_ERR_NOMEM, "io");
+    typename mspoly::TransposeOutKernel<F>::Params p{d_lde.as<T>(), d_io.as<u64>(), L, lde_c, L};
+    CK(msrt::launch<mspoly::TransposeOutKernel<F>>(stream, grid1(tot, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    CK(msrt::d2h(out, d_io.p, tot * 8, stream));
+    CK(msrt::sync(stream));
+    return MS_OK;
+  }
+  // ------------------------------------------------------------------ starks.rs:108-119
+  int mix(u64 r) override {
+    if (!have_polys) return fail(MS_ERR_STATE, "mix before interpolate");
+    if (r >= F::P) return fail(MS_ERR_ARG, "r not canonical");
+    RQ(ensure_polys(npolys + 1));
+    typename mspoly::MixKernel<F>::Params p{d_polys.as<T>(), N, N, npolys, F::from_u64(r), d_polys.as<T>() + (size_t)npolys * N};
+    CK(msrt::launch<mspoly::MixKernel<F>>(stream, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    have_validity = true; nrounds_done = 0;
+    return MS_OK;
+  }
+  int validity_read(u64* out) override {
+    if (!have_validity || !out) return fail(MS_ERR_STATE, "validity_read");
+    return download_widen(d_polys.as<T>() + (size_t)npolys * N, N, 0, 1, out);
+  }
+
+  // evaluate `npoly` polynomials (views) at ext point z into d_small[out_slot .. ) as [npoly][E] T
+  template <int EC>
+  int eval_views(const T* base, size_t poly_stride, size_t limb_stride, size_t kstride, const size_t* off, const size_t* count, int npoly, const XE& z, T* dst) {
+    size_t maxc = 0;
+    for (int i = 0; i < npoly; i++) if (count[i] > maxc) maxc = count[i];
+    typedef mspoly::EvalKernel<F, EC, E> EK;
+    const size_t chunk = (size_t)EK::THREADS * EK::ITEMS;
+    const size_t nblocks = maxc ? (maxc + chunk - 1) / chunk : 1;
+    if (d_partials.ensure(nblocks * npoly * E * sizeof(T))) return fail(MS_ERR_NOMEM, "partials");
+    typename EK::Params p;
+    p.base = base; p.poly_stride = poly_stride; p.limb_stride = limb_stride; p.kstride = kstride; p.npoly = npoly;
+    for (int i = 0; i < mspoly::MAX_POLYS; i++) { p.off[i] = i < npoly ? off[i] : 0; p.count[i] = i < npoly ? count[i] : 0; }
+    p.z = z; p.z_step = e_pow<F, E>(z, EK::THREADS); p.partials = d_partials.as<T>();
+    CK(msrt::launch<EK>(stream, (unsigned)nblocks, 1, EK::THREADS, EK::lds_bytes(), p));
+    typename mspoly::ReducePartialsKernel<F>::Params rp{d_partials.as<T>(), nblocks, npoly * E, dst};
+    CK(msrt::launch<mspoly::ReducePartialsKernel<F>>(stream, 1, 1, mspoly::ReducePartialsKernel<F>::THREADS, 0, rp));
+    return 0;
+  }
+  static bool load_ext(const u64* v, XE* out) { for (int l = 0; l < E; l++) { if (v[l] >= F::P) return false; out->c[l] = F::from_u64(v[l]); } return true; }
+
+  // ------------------------------------------------------------------ starks.rs:124-151
+  int eval_ext(const u64* z, int q, u64* out) override {
+    if (!have_validity) return fail(MS_ERR_STATE, "eval_ext before mix");
+    if (!z || !out || q < 0) return fail(MS_ERR_ARG, "eval_ext");
+    const int np = npolys + 1;
+    const size_t tot = (size_t)q * np * E;
+    if (d_small.ensure(tot * sizeof(T) + 4096)) return fail(MS_ERR_NOMEM, "small");
+    if (tot * sizeof(T) > pinned_cap) return fail(MS_ERR_ARG, "too many evaluation points");
+    for (int t = 0; t < q; t++) {
+      XE zz;
+      if (!load_ext(z + (size_t)t * E, &zz)) return fail(MS_ERR_ARG, "query point not canonical");
+      for (int i0 = 0; i0 < np; i0 += mspoly::MAX_POLYS) {
+        const int nb = (np - i0 < mspoly::MAX_POLYS) ? np - i0 : mspoly::MAX_POLYS;
+        size_t off[mspoly::MAX_POLYS], cnt[mspoly::MAX_POLYS];
+        for (int i = 0; i < nb; i++) { off[i] = 0; cnt[i] = N; }
+        RQ((eval_views<1>(d_polys.as<T>() + (size_t)i0 * N, N, 0, 1, off, cnt, nb, zz, d_small.as<T>() + ((size_t)t * np + i0) * E)));
+      }
+    }
+    if (tot) {
+      CK(msrt::d2h(pinned, d_small.p, tot * sizeof(T), stream));
+      CK(msrt::sync(stream));
+      const T* h = reinterpret_cast<const T*>(pinned);
+      for (size_t i = 0; i < tot; i++) out[i] = F::to_u64(h[i]);
+    }
+    return MS_OK;
+  }
+
+  // ------------------------------------------------------------------ FRI rounds (fri.rs:314-352)
+  Round* round_slot(size_t i) { while (rounds.size() <= i) rounds.push_back(new Round()); return rounds[i]; }
+  // codeword + tree of rounds[i] from its coefficient limbs (ncoef_in valid coefficients)
+  int round_commit(Round* r, size_t ncoef_in) {
+    if (ctz64(r->D) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "FRI domain larger than the field's two-adicity");
+    RQ(tree_shape(r->D, 2, 2, &r->ts));  // starks.rs:290-295: leafs_per_node 2, inner_children 2
+    if (r->cw.ensure(r->D * E * sizeof(T))) return fail(MS_ERR_NOMEM, "codeword");
+    RQ(ntt_run(ctz64(r->D), false, r->poly.template as<T>(), r->cap, ncoef_in, r->cw.template as<T>(), r->D, E));  // fri.rs:350
+    RQ((tree_build<E>(r->cw.template as<T>(), 0, 1, r->D, 1, r->ts, r->nodes)));                                       // fri.rs:351
+    return 0;
+  }
+  int read_degree_and_root(const T* poly, size_t limb_stride, size_t n, Round* r, size_t* ncoef, u8* root) {
+    if (d_deg.ensure(64)) return fail(MS_ERR_NOMEM, "deg");
+    unsigned long long* dres = d_deg.as<unsigned long long>();
+    CK(msrt::memset_dev(dres, 0, 8, stream));
+    if (n) {
+      typename mspoly::DegreeKernel<F, E>::Params dp{poly, limb_stride, n, dres};
+      CK(msrt::launch<mspoly::DegreeKernel<F, E>>(stream, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
+    }
+    CK(msrt::d2h(pinned, dres, 8, stream));
+    if (r) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, r->nodes.template as<u8>() + (r->ts.nodes - 1) * 32, 32, stream));
+    CK(msrt::sync(stream));
+    *ncoef = (size_t)(*reinterpret_cast<unsigned long long*>(pinned));
+    if (r && root) memcpy(root, reinterpret_cast<u8*>(pinned) + 64, 32);
+    return 0;
+  }
+  // fri.rs:73-82
+  int fri_begin(size_t blowup_, size_t nrounds, u8* root0) override {
+    if (!have_validity) return fail(MS_ERR_STATE, "fri_begin before mix");
+    if (!root0 || nrounds < 1 || !blowup_) return fail(MS_ERR_ARG, "fri_begin");
+    nrounds_done = 0; have_deep = false; blob_size = 0;
+    fri_rounds = nrounds; fri_blowup = blowup_;
+    Round* r = round_slot(0);
+    r->cap = N;
+    if (r->poly.ensure(N * E * sizeof(T))) return fail(MS_ERR_NOMEM, "round poly");
+    // field.rs:23-32 extend_poly: limb 0 = validity, higher limbs zero
+    CK(msrt::memset_dev(r->poly.p, 0, N * E * sizeof(T), stream));
+    CK(msrt::d2d(r->poly.p, d_polys.as<T>() + (size_t)npolys * N, N * sizeof(T), stream));
+    size_t nc;
+    RQ(read_degree_and_root(r->poly.template as<T>(), r->cap, N, nullptr, &nc, nullptr));
+    r->ncoef = nc;
+    const size_t deg = nc ? nc - 1 : 0;
+    size_t dsize = (deg + 1) * blowup_;  // fri.rs:74 (quirk Q11)
+    size_t D = 1; while (D < dsize) D <<= 1;
+    r->D = D;
+    RQ(round_commit(r, nc));
+    RQ(read_root(r->nodes, r->ts, root0));
+    nrounds_done = 1;
+    return MS_OK;
+  }
+  // fri.rs:89-94
+  int fri_deep(const u64* z, u64* B) override {
+    if (nrounds_done == 0 || nrounds_done >= fri_rounds) return fail(MS_ERR_STATE, "fri_deep out of order");
+    if (!z || !B) return fail(MS_ERR_ARG, "fri_deep");
+    if (!load_ext(z, &cur_z)) return fail(MS_ERR_ARG, "z not canonical");
+    Round* r = rounds[nrounds_done - 1];
+    size_t off[2] = {0, 1}, cnt[2] = {(r->ncoef + 1) / 2, r->ncoef / 2};
+    T* dst = d_small.as<T>();
+    RQ((eval_views<E>(r->poly.template as<T>(), 0, r->cap, 2, off, cnt, 2, cur_z, dst)));  // fri.rs:354-359
+    CK(msrt::d2h(pinned, dst, 2 * E * sizeof(T), stream));
+    CK(msrt::sync(stream));
+    const T* h = reinterpret_cast<const T*>(pinned);
+    for (int s = 0; s < 2; s++) for (int l = 0; l < E; l++) { cur_B[s].c[l] = h[s * E + l]; B[s * E + l] = F::to_u64(h[s * E + l]); }
+    have_deep = true;
+    return MS_OK;
+  }
+
+  // multi-level suffix Horner: H_j of the view (m elements) with multiplier z.
+  // q_{j-1} = H_j goes to `out` (typed OutT), H_0 to h0 (may be null).
+  template <class OutT>
+  int suffix_horner(const T* in, size_t in_limb_stride, size_t in_off, size_t in_stride, size_t m, const XE& z,
+                    OutT* out, size_t out_limb_stride, size_t out_off, size_t out_stride, T* h0) {
+    if (m == 0) return 0;
+    const size_t BS = mspoly::SH_BS;
+    std::vector<size_t> ms; ms.push_back(m);
+    while ((ms.back() + BS - 1) / BS > 1) ms.push_back((ms.back() + BS - 1) / BS);
+    const int nl = (int)ms.size();
+    // level buffers: agg_l (input of level l+1) and carry_l, each E * nb_l
+    std::vector<size_t> aoff(nl), coff(nl);
+    size_t tot = 0;
+    for (int l = 0; l < nl; l++) { size_t nb = (ms[l] + BS - 1) / BS; aoff[l] = tot; tot += nb * E; coff[l] = tot; tot += nb * E; }
+    if (d_sh.ensure(tot * sizeof(T))) return fail(MS_ERR_NOMEM, "scan levels");
+    T* base = d_sh.as<T>();
+    std::vector<XE> zl(nl); zl[0] = z;
+    std::vector<std::vector<XE>> zp(nl, std::vector<XE>(9));
+    for (int l = 0; l < nl; l++) {
+      XE s = e_pow<F, E>(zl[l], mspoly::SH_SEG);
+      for (int i = 0; i < 9; i++) { zp[l][i] = s; s = e_mul<F>(s, s); }
+      if (l + 1 < nl) zl[l + 1] = zp[l][8];  // z^(SEG*256) = z^BS
+    }
+    typedef mspoly::SuffixHornerKernel<F, E, T> KT;
+    typedef mspoly::SuffixHornerKernel<F, E, OutT> KO;
+    auto fill = [&](auto& p, int l) {
+      p.zs = nullptr; p.in_boff = p.out_boff = p.h0_boff = p.agg_boff = p.carry_boff = 0;
+      p.z = zl[l]; for (int i = 0; i < 9; i++) p.zpow[i] = zp[l][i];
+      p.m = ms[l];
+      if (l == 0) { p.in = in; p.in_limb_stride = in_limb_stride; p.in_off = in_off; p.in_stride = in_stride; }
+      else { p.in = base + aoff[l - 1]; p.in_limb_stride = (ms[l - 1] + BS - 1) / BS; p.in_off = 0; p.in_stride = 1; }
+      p.agg = nullptr; p.agg_limb_stride = 0; p.carry = nullptr; p.carry_limb_stride = 0;
+      p.out = nullptr; p.out_limb_stride = 0; p.out_off = 0; p.out_stride = 1; p.h0 = nullptr;
+    };
+    for (int l = 0; l + 1 < nl; l++) {  // aggregates, bottom-up
+      typename KT::Params p; fill(p, l);
+      const size_t nb = (ms[l] + BS - 1) / BS;
+      p.final_mode = 0; p.agg = base + aoff[l]; p.agg_limb_stride = nb;
+      CK(msrt::launch<KT>(stream, (unsigned)nb, 1, KT::THREADS, KT::lds_bytes(), p));
+    }
+    for (int l = nl - 1; l >= 0; l--) {  // finals, top-down
+      const size_t nb = (ms[l] + BS - 1) / BS;
+      const bool has_carry = (l + 1 < nl);
+      if (l > 0) {
+        typename KT::Params p; fill(p, l);
+        p.final_mode = 1;
+        if (has_carry) { p.carry = base + coff[l]; p.carry_limb_stride = nb; }
+        // this level's H_{b+1} is the carry-in of block b one level down
+        const size_t nb_below = ms[l];  // == number of blocks at level l-1
+        CK(msrt::memset_dev(base + coff[l - 1], 0, nb_below * E * sizeof(T), stream));
+        p.out = base + coff[l - 1]; p.out_limb_stride = nb_below; p.out_off = 0; p.out_stride = 1;
+        CK(msrt::launch<KT>(stream, (unsigned)nb, 1, KT::THREADS, KT::lds_bytes(), p));
+      } else {
+        typename KO::Params p; fill(p, l);
+        p.final_mode = 1;
+        if (has_carry) { p.carry = base + coff[l]; p.carry_limb_stride = nb; }
+        p.out = out; p.out_limb_stride = out_limb_stride; p.out_off = out_off; p.out_stride = out_stride; p.h0 = h0;
+        CK(msrt::launch<KO>(stream, (unsigned)nb, 1, KO::THREADS, KO::lds_bytes(), p));
+      }
+    }
+    return 0;
+  }
+
+  // fri.rs:96-109
+  int fri_fold_commit(const u64* alpha, u8* root) override {
+    if (!have_deep) return fail(MS_ERR_STATE, "fri_fold_commit before fri_deep");
+    XE a;
+    if (!alpha || !root || !load_ext(alpha, &a)) return fail(MS_ERR_ARG, "alpha");
+    Round* pr = rounds[nrounds_done - 1];
+    if (pr->D < 4) return fail(MS_ERR_SHAPE, "FRI round domain too small to fold (merkle.rs:93-104 panics)");
+    const size_t n = pr->ncoef, m = (n + 1) / 2;
+    Round* nr = round_slot(nrounds_done);
+    nr->cap = m ? m : 1;
+    nr->D = pr->D / 2;  // fri.rs:104, 374-376
+    if (nr->poly.ensure(nr->cap * E * sizeof(T)) || d_folded.ensure((m + 1) * E * sizeof(T))) return fail(MS_ERR_NOMEM, "fold");
+    size_t nq_coef = 0;
+    if (m >= 2) {
+      typename mspoly::FoldKernel<F, E>::Params fp{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a};  // fri.rs:361-372
+      CK(msrt::launch<mspoly::FoldKernel<F, E>>(stream, grid1(m, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
+      // (folded - B(alpha)) / (x - z): quotient coefficients are H_1.. of the suffix Horner in z (fri.rs:99-101)
+      RQ((suffix_horner<T>(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), nr->cap, 0, 1, nullptr)));
+      nq_coef = m - 1;
+    }
+    RQ(round_commit(nr, nq_coef));
+    size_t nc;
+    RQ(read_degree_and_root(nr->poly.template as<T>(), nr->cap, nq_coef, nr, &nc, root));
+    nr->ncoef = nc;
+    nrounds_done++; have_deep = false;
+    return MS_OK;
+  }
+  int fri_round_info(int r, u64* ncoef, u64* D) override {
+    if (r < 0 || (size_t)r >= nrounds_done) return fail(MS_ERR_ARG, "round index");
+    if (ncoef) *ncoef = rounds[r]->ncoef;
+    if (D) *D = rounds[r]->D;
+    return MS_OK;
+  }
+  int fri_round_poly_read(int r, u64* out) override {
+    if (r < 0 || (size_t)r >= nrounds_done || !out) return fail(MS_ERR_ARG, "round index");
+    return download_widen(rounds[r]->poly.template as<T>(), rounds[r]->ncoef, rounds[r]->cap, E, out);
+  }
+  int fri_round_codeword_read(int r, u64* out) override {
+    if (r < 0 || (size_t)r >= nrounds_done || !out) return fail(MS_ERR_ARG, "round index");
+    return download_widen(rounds[r]->cw.template as<T>(), rounds[r]->D, rounds[r]->D, E, out);
+  }
+
+  // ------------------------------------------------------------------ fri.rs:115-189
+  int fri_query(const u64* betas, int nq) override {
+    if (nrounds_done != fri_rounds || fri_rounds == 0) return fail(MS_ERR_STATE, "fri_query before the commit phase finished");
+    if (!betas || nq < 1) return fail(MS_ERR_ARG, "fri_query");
+    const size_t W = fri_rounds - 1;  // windows
+    // ---- layout of the MSFP blob
+    std::vector<size_t> rec_off(W * nq), path_off(W * nq * 2), qlen(W);
+    size_t pos = 0;
+    for (size_t i = 0; i < W; i++) {
+      Round* pr = rounds[i];
+      if (pr->D / 2 != rounds[i + 1]->D) return fail(MS_ERR_SHAPE, "round domains do not halve (fri.rs:134-137)");
+      qlen[i] = pr->ncoef >= 3 ? pr->ncoef - 2 : 0;
+      const size_t nlev = pr->ts.levels - 1;
+      const size_t path_bytes = 8 + 2 * E * 8 + 8 + nlev * 2 * 32;
+      for (int j = 0; j < nq; j++) {
+        rec_off[i * nq + j] = pos;
+        pos += 6 * E * 8 + 8 + qlen[i] * E * 8;
+        path_off[(i * nq + j) * 2] = pos; pos += path_bytes;
+        path_off[(i * nq + j) * 2 + 1] = pos; pos += path_bytes;
+      }
+    }
+    if (d_blob.ensure(pos + 8)) return fail(MS_ERR_NOMEM, "proof blob");
+    blob_size = 0;
+    // ---- per-window scalars and offset tables, one upload
+    const size_t n_off = W * nq * 3;
+    std::vector<u8> tab(n_off * sizeof(size_t) + W * nq * 2 * sizeof(T) + W * nq * 8);
+    size_t* t_rec = reinterpret_cast<size_t*>(tab.data());
+    size_t* t_path = t_rec + W * nq;
+    T* t_x1 = reinterpret_cast<T*>(tab.data() + n_off * sizeof(size_t));
+    T* t_x3 = t_x1 + W * nq;
+    u64* t_qlen = reinterpret_cast<u64*>(tab.data() + n_off * sizeof(size_t) + W * nq * 2 * sizeof(T));
+    std::vector<T> x3h(W * nq);
+    for (size_t i = 0; i < W; i++) {
+      Round* pr = rounds[i];
+      const T gp = f_root_of_unity<F>(ctz64(pr->D));
+      for (int j = 0; j < nq; j++) {
+        u64 beta = betas[j];
+        if (beta > pr->D) beta %= pr->D;  // fri.rs:144-146 (quirk Q6)
+        const T x1 = f_pow<F>(gp, beta);  // fri.rs:148
+        const T x3 = F::mul(x1, x1);      // fri.rs:150: round.domain.element(beta) == x1^2
+        t_rec[i * nq + j] = rec_off[i * nq + j];
+        t_path[(i * nq + j) * 2] = path_off[(i * nq + j) * 2];
+        t_path[(i * nq + j) * 2 + 1] = path_off[(i * nq + j) * 2 + 1];
+        t_x1[i * nq + j] = x1; t_x3[i * nq + j] = x3; x3h[i * nq + j] = x3;
+        t_qlen[i * nq + j] = qlen[i];
+      }
+    }
+    if (d_tabs.ensure(tab.size()) || d_targets.ensure((size_t)nq * (2 + 3) * E * sizeof(T)) || d_idx.ensure(W * nq * 2 * 8)) return fail(MS_ERR_NOMEM, "query tables");
+    CK(msrt::h2d(d_tabs.p, tab.data(), tab.size(), stream));
+    CK(msrt::sync(stream));  // `tab` is pageable host memory: keep it alive until the copy is done
+    const size_t* dt_rec = d_tabs.as<size_t>();
+    const size_t* dt_path = dt_rec + W * nq;
+    const T* dt_x1 = reinterpret_cast<const T*>(d_tabs.as<u8>() + n_off * sizeof(size_t));
+    const T* dt_x3 = dt_x1 + W * nq;
+    const u64* dt_qlen = reinterpret_cast<const u64*>(d_tabs.as<u8>() + n_off * sizeof(size_t) + W * nq * 2 * sizeof(T));
+    CK(msrt::memset_dev(d_idx.p, 0xFF, W * nq * 2 * 8, stream));
+    T* d_tg = d_targets.as<T>();            // [2nq][E] find-first targets
+    T* d_h0e = d_tg + (size_t)2 * nq * E;   // [nq][E]
+    T* d_h0o = d_h0e + (size_t)nq * E;
+    T* d_y3 = d_h0o + (size_t)nq * E;
+    u8* blob = d_blob.as<u8>();
+    for (size_t i = 0; i < W; i++) {
+      Round* pr = rounds[i]; Round* cr = rounds[i + 1];
+      const size_t n = pr->ncoef, me = (n + 1) / 2, mo = n / 2;
+      for (int j = 0; j < nq; j++) {
+        const XE X3 = e_from_base<F, E>(x3h[i * nq + j]);
+        u64* rec = reinterpret_cast<u64*>(blob + rec_off[i * nq + j]);
+        u64* qout = rec + 6 * E + 1;
+        // qlen word (fri.rs:167 `q.to_vec()` length)
+        CK(msrt::d2d(rec + 6 * E, dt_qlen + i * nq + j, 8, stream));
+        // (f - g)/((x-x1)(x-x2)) = Qe(x^2) + x Qo(x^2), Qe = (even(y)-even(x3))/(y-x3), same for odd (fri.rs:159-167);
+        // the suffix Horner also yields even(x3), odd(x3) as H_0
+        CK(msrt::memset_dev(d_h0e + (size_t)j * E, 0, E * sizeof(T), stream));
+        CK(msrt::memset_dev(d_h0o + (size_t)j * E, 0, E * sizeof(T), stream));
+        RQ((suffix_horner<u64>(pr->poly.template as<T>(), pr->cap, 0, 2, me, X3, qout, 1, 0, 2 * E, d_h0e + (size_t)j * E)));
+        RQ((suffix_horner<u64>(pr->poly.template as<T>(), pr->cap, 1, 2, mo, X3, qout, 1, E, 2 * E, d_h0o + (size_t)j * E)));
+        size_t off1[1] = {0}, cnt1[1] = {cr->ncoef};
+        RQ((eval_views<E>(cr->poly.template as<T>(), 0, cr->cap, 1, off1, cnt1, 1, X3, d_y3 + (size_t)j * E)));  // fri.rs:153
+      }
+      typename mspoly::QueryPointsKernel<F, E>::Params qp{d_h0e, d_h0o, d_y3, dt_x1 + i * nq, dt_x3 + i * nq, nq, blob, dt_rec + i * nq, d_tg};
+      CK(msrt::launch<mspoly::QueryPointsKernel<F, E>>(stream, grid1(nq, 64), 1, 64, 0, qp));
+      unsigned long long* didx = d_idx.as<unsigned long long>() + i * nq * 2;
+      typename mspoly::FindFirstKernel<F, E>::Params ff{pr->cw.template as<T>(), pr->D, pr->D, d_tg, 2 * nq, didx};  // merkle.rs:216-225
+      CK(msrt::launch<mspoly::FindFirstKernel<F, E>>(stream, grid1(pr->D, mspoly::THREADS), 1, mspoly::THREADS, 0, ff));
+      typename msmerkle::PathKernel<F, E>::Params pk{pr->cw.template as<T>(), pr->D, pr->nodes.template as<u32>(), pr->D, 2, 2, (u32)(pr->ts.levels - 1), didx, (u32)(2 * nq), blob, dt_path + i * nq * 2};
+      // the path kernel must not run for a value that was not found: checked after the loop via d_idx,
+      // and PathKernel clamps nothing, so guard by launching it only after verifying on the host when D is tiny.
+      CK(msrt::launch<msmerkle::PathKernel<F, E>>(stream, grid1(2 * nq, 64), 1, 64, 0, pk));
+    }
+    if (W * nq * 2 * 8 > pinned_cap) return fail(MS_ERR_ARG, "too many queries");
+    CK(msrt::d2h(pinned, d_idx.p, W * nq * 2 * 8, stream));
+    CK(msrt::sync(stream));
+    const unsigned long long* hidx = reinterpret_cast<const unsigned long long*>(pinned);
+    for (size_t t = 0; t < W * nq * 2; t++) if (hidx[t] == ~0ULL) return fail(MS_ERR_LEAF_NOT_FOUND, "leaf is not included in the tree");
+    blob_size = pos;
+    return MS_OK;
+  }
+  size_t fri_proof_size() const override { return blob_size; }
+  int fri_proof_read(u8* out) override {
+    if (!blob_size || !out) return fail(MS_ERR_STATE, "no FRI proof");
+    CK(msrt::d2h(out, d_blob.p, blob_size, stream));
+    CK(msrt::sync(stream));
+    return MS_OK;
+  }
+
+  // ------------------------------------------------------------------ standalone entry points
+  int merkle_commit(const u64* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, u8* nodes_out, size_t cap, size_t* nn, u8* root) override {
+    if (!leafs && leaf_num) return fail(MS_ERR_ARG, "null leafs");
+    if (ext != 1 && ext != E) return fail(MS_ERR_ARG, "ext must be 1 or the field's extension degree");
+    TreeShape ts;
+    RQ(tree_shape(leaf_num, lpn, ic, &ts));
+    if (!canonical(leafs, leaf_num * ext)) return fail(MS_ERR_ARG, "leaf not canonical");
+    DevBuf dl, dn;
+    if (dl.ensure(leaf_num * ext * sizeof(T))) return fail(MS_ERR_NOMEM, "leafs");
+    int rc = upload_narrow(leafs, leaf_num * ext, dl.as<T>());
+    // AoS view: element f limb k at base + f*ext + k
+    if (!rc) rc = (ext == 1) ? tree_build<1>(dl.as<T>(), 0, 1, 0, 1, ts, dn) : tree_build<E>(dl.as<T>(), 0, (size_t)ext, 1, 1, ts, dn);
+    if (!rc && nn) *nn = ts.nodes;
+    if (!rc && nodes_out) {
+      if (cap < ts.nodes) rc = fail(MS_ERR_ARG, "nodes_out too small");
+      else { int e = msrt::d2h(nodes_out, dn.p, ts.nodes * 32, stream); if (!e) e = msrt::sync(stream); if (e) rc = fail_rt(e, "nodes d2h"); }
+    }
+    if (!rc && root) rc = read_root(dn, ts, root);
+    msrt::sync(stream);
+    dl.release(); dn.release();
+    return rc;
+  }
+  int ntt(u64* data, size_t n, size_t batch, int inverse) override {
+    if (!data || !n || !is_pow2(n)) return fail(MS_ERR_SHAPE, "ntt size must be a power of two");
+    if (ctz64(n) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "ntt size exceeds two-adicity");
+    if (!canonical(data, n * batch)) return fail(MS_ERR_ARG, "element not canonical");
+    DevBuf d;
+    if (d.ensure(n * batch * sizeof(T))) return fail(MS_ERR_NOMEM, "ntt buffer");
+    int rc = upload_narrow(data, n * batch, d.as<T>());
+    if (!rc) rc = ntt_run(ctz64(n), inverse != 0, d.as<T>(), n, n, d.as<T>(), n, batch);
+    if (!rc) rc = download_widen(d.as<T>(), n * batch, 0, 1, data);
+    msrt::sync(stream);
+    d.release();
+    return rc;
+  }
+  int coset_lde(const u64* coeffs, size_t ncoef, size_t batch, u64 shift, u64* out, size_t L_) override {
+    if (!coeffs || !out || !L_ || !is_pow2(L_) || ncoef > L_ || !ncoef) return fail(MS_ERR_SHAPE, "coset_lde shape");
+    if (ctz64(L_) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "domain exceeds two-adicity");
+    if (shift == 0 || shift >= F::P || !canonical(coeffs, ncoef * batch)) return fail(MS_ERR_ARG, "not canonical");
+    DevBuf a, b;
+    if (a.ensure(ncoef * batch * sizeof(T)) || b.ensure(L_ * batch * sizeof(T))) return fail(MS_ERR_NOMEM, "lde buffers");
+    int rc = upload_narrow(coeffs, ncoef * batch, a.as<T>());
+    if (!rc) {
+      typename msntt::ScalePowKernel<F>::Params sp;
+      sp.src = a.as<T>(); sp.dst = a.as<T>(); sp.src_bstride = ncoef; sp.dst_bstride = ncoef; sp.n = ncoef;
+      sp.s = F::from_u64(shift); sp.s_step = f_pow<F>(sp.s, msntt::ScalePowKernel<F>::THREADS);
+      const int per_block = msntt::ScalePowKernel<F>::THREADS * msntt::ScalePowKernel<F>::ITEMS;
+      int e = msrt::launch<msntt::ScalePowKernel<F>>(stream, grid1(ncoef, per_block), (unsigned)batch, msntt::ScalePowKernel<F>::THREADS, 0, sp);
+      if (e) rc = fail_rt(e, "scale");
+    }
+    if (!rc) rc = ntt_run(ctz64(L_), false, a.as<T>(), ncoef, ncoef, b.as<T>(), L_, batch);
+    if (!rc) rc = download_widen(b.as<T>(), L_ * batch, 0, 1, out);
+    msrt::sync(stream);
+    a.release(); b.release();
+    return rc;
+  }
+};
+
+inline CtxBase* B(ms_ctx* c) { return reinterpret_cast<CtxBase*>(c); }
+inline const CtxBase* B(const ms_ctx* c) { return reinterpret_cast<const CtxBase*>(c); }
+
+}  // namespace
+
+extern "C" {
+
+int ms_create(ms_ctx** out, int device, ms_field field, uint32_t flags) {
+  if (!out) return MS_ERR_ARG;
+  *out = nullptr;
+  int rc;
+  if (field == MS_FIELD_GOLDILOCKS) { auto* c = new Ctx<GL>(); rc = c->init(device, flags); if (rc) { delete c; return rc; } *out = reinterpret_cast<ms_ctx*>(static_cast<CtxBase*>(c)); }
+  else if (field == MS_FIELD_BABYBEAR) { auto* c = new Ctx<BB>(); rc = c->init(device, flags); if (rc) { delete c; return rc; } *out = reinterpret_cast<ms_ctx*>(static_cast<CtxBase*>(c)); }
+  else return MS_ERR_ARG;
+  return MS_OK;
+}
+void ms_destroy(ms_ctx* ctx) { delete B(ctx); }
+const char* ms_last_error(const ms_ctx* ctx) { return ctx ? B(ctx)->err.c_str() : "null context"; }
+int ms_ext_degree(const ms_ctx* ctx) { return ctx ? B(ctx)->ext_degree() : MS_ERR_ARG; }
+int ms_set_stream(ms_ctx* ctx, void* s) { return ctx ? B(ctx)->set_stream(s) : MS_ERR_ARG; }
+int ms_synchronize(ms_ctx* ctx) { return ctx ? B(ctx)->synchronize() : MS_ERR_ARG; }
+
+int ms_is_power_of_two(uint64_t n) { return is_pow2(n) ? 1 : 0; }
+long ms_logarithm_of_two_k(uint64_t n, uint64_t base) { return log_two_k(n, base); }
+uint64_t ms_ceil_log2_k(uint64_t n, uint64_t base) { return ceil_log2_k(n, base); }
+// src/starks.rs:312-332
+int ms_num_queries(ms_field f, uint64_t security_bits, uint64_t blowup, uint64_t steps, uint64_t* linking, uint64_t* fri) {
+  if (!linking || !fri || !blowup || !steps) return MS_ERR_ARG;
+  if (security_bits < 20) return MS_ERR_SHAPE;  // starks.rs:317-320 panics
+  const u64 modulus_bits = (f == MS_FIELD_GOLDILOCKS) ? 64 : 31;
+  const u64 log_steps = ceil_log2_k(steps, 2);
+  const u64 den = modulus_bits - log_steps;
+  *linking = (security_bits + den - 1) / den;
+  const u64 rounds = ceil_log2_k(steps * blowup, 2);
+  const double rho = 1.0 / (double)blowup;
+  const double denominator = __builtin_log2(2.0 / (1.0 + rho));
+  const double total = (double)security_bits / denominator;
+  *fri = (u64)__builtin_ceil(total / (double)rounds);
+  return MS_OK;
+}
+uint64_t ms_root_of_unity(ms_field f, uint64_t n) {
+  if (!n || !is_pow2(n)) return 0;
+  const int lg = ctz64(n);
+  if (f == MS_FIELD_GOLDILOCKS) return lg <= GL::TWO_ADICITY ? GL::to_u64(f_root_of_unity<GL>(lg)) : 0;
+  return lg <= BB::TWO_ADICITY ? BB::to_u64(f_root_of_unity<BB>(lg)) : 0;
+}
+
+#define CTX_OR_FAIL if (!ctx) return MS_ERR_ARG
+int ms_trace_commit(ms_ctx* ctx, const uint64_t* t, size_t N, size_t w, size_t lpn, uint8_t root[32]) { CTX_OR_FAIL; return B(ctx)->trace_commit(t, false, N, w, lpn, root); }
+int ms_trace_commit_device(ms_ctx* ctx, const void* t, size_t N, size_t w, size_t lpn, uint8_t root[32]) { CTX_OR_FAIL; return B(ctx)->trace_commit(reinterpret_cast<const u64*>(t), true, N, w, lpn, root); }
+int ms_interpolate(ms_ctx* ctx) { CTX_OR_FAIL; return B(ctx)->interpolate(); }
+int ms_polys_lincomb(ms_ctx* ctx, const uint64_t* s, const int* idx, int k) { CTX_OR_FAIL; return B(ctx)->polys_lincomb(s, idx, k); }
+int ms_polys_append(ms_ctx* ctx, const uint64_t* c, size_t n) { CTX_OR_FAIL; return B(ctx)->polys_append(c, n); }
+int ms_polys_count(const ms_ctx* ctx) { CTX_OR_FAIL; return B(ctx)->polys_count(); }
+int ms_poly_read(ms_ctx* ctx, int i, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->poly_read(i, out); }
+int ms_lde_commit(ms_ctx* ctx, size_t blowup, uint64_t shift, size_t lpn, uint8_t root[32]) { CTX_OR_FAIL; return B(ctx)->lde_commit(blowup, shift, lpn, root); }
+int ms_lde_read(ms_ctx* ctx, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->lde_read(out); }
+int ms_mix(ms_ctx* ctx, uint64_t r) { CTX_OR_FAIL; return B(ctx)->mix(r); }
+int ms_validity_read(ms_ctx* ctx, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->validity_read(out); }
+int ms_eval_ext(ms_ctx* ctx, const uint64_t* z, int q, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->eval_ext(z, q, out); }
+int ms_fri_begin(ms_ctx* ctx, size_t blowup, size_t rounds, uint8_t root0[32]) { CTX_OR_FAIL; return B(ctx)->fri_begin(blowup, rounds, root0); }
+int ms_fri_deep(ms_ctx* ctx, const uint64_t* z, uint64_t* Bv) { CTX_OR_FAIL; return B(ctx)->fri_deep(z, Bv); }
+int ms_fri_fold_commit(ms_ctx* ctx, const uint64_t* a, uint8_t root[32]) { CTX_OR_FAIL; return B(ctx)->fri_fold_commit(a, root); }
+int ms_fri_round_info(ms_ctx* ctx, int r, uint64_t* nc, uint64_t* D) { CTX_OR_FAIL; return B(ctx)->fri_round_info(r, nc, D); }
+int ms_fri_round_poly_read(ms_ctx* ctx, int r, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->fri_round_poly_read(r, out); }
+int ms_fri_round_codeword_read(ms_ctx* ctx, int r, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->fri_round_codeword_read(r, out); }
+int ms_fri_query(ms_ctx* ctx, const uint64_t* betas, int nq) { CTX_OR_FAIL; return B(ctx)->fri_query(betas, nq); }
+size_t ms_fri_proof_size(const ms_ctx* ctx) { return ctx ? B(ctx)->fri_proof_size() : 0; }
+int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out) { CTX_OR_FAIL; return B(ctx)->fri_proof_read(out); }
+int ms_merkle_commit(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, uint8_t* nodes_out, size_t cap, size_t* nn, uint8_t root[32]) {
+  CTX_OR_FAIL; return B(ctx)->merkle_commit(leafs, leaf_num, ext, lpn, ic, nodes_out, cap, nn, root);
+}
+int ms_ntt(ms_ctx* ctx, uint64_t* data, size_t n, size_t batch, int inverse) { CTX_OR_FAIL; return B(ctx)->ntt(data, n, batch, inverse); }
+int ms_coset_lde(ms_ctx* ctx, const uint64_t* c, size_t ncoef, size_t batch, uint64_t shift, uint64_t* out, size_t L) { CTX_OR_FAIL; return B(ctx)->coset_lde(c, ncoef, batch, shift, out, L); }
+int ms_bench_lde(ms_ctx* ctx, size_t blowup, uint64_t shift) { CTX_OR_FAIL; return B(ctx)->bench_lde(blowup, shift); }
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// rt.hpp — thin runtime layer under the kernels.
+//
+// Kernels are written as structs with a Params block and a `phase()` function:
+// every workgroup barrier sits BETWEEN phases and no per-thread state survives
+// a phase.  On the GPU `ms_kmain<K>` runs the phases with `__syncthreads()`
+// between them.  With -DMS_EMU (tests/emu only — never shipped, never loaded by
+// the product) the same phase code is executed thread by thread on the CPU so
+// kernel logic can be checked against the oracle without a GPU.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+#if defined(MS_EMU)
+#include <cstdlib>
+#include <vector>
+#define MS_HD inline
+#define MS_DEV inline
+#define MS_RESTRICT
+namespace msrt {
+struct Stream { int dummy; };
+inline int malloc_dev(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
+inline int free_dev(void* p) { std::free(p); return 0; }
+inline int malloc_host(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
+inline int free_host(void* p) { std::free(p); return 0; }
+inline int h2d(void* d, const void* h, size_t n, Stream*) { std::memcpy(d, h, n); return 0; }
+inline int d2h(void* h, const void* d, size_t n, Stream*) { std::memcpy(h, d, n); return 0; }
+inline int d2d(void* d, const void* s, size_t n, Stream*) { std::memmove(d, s, n); return 0; }
+inline int memset_dev(void* d, int v, size_t n, Stream*) { std::memset(d, v, n); return 0; }
+inline int sync(Stream*) { return 0; }
+inline int stream_create(Stream** s) { *s = new Stream(); return 0; }
+inline int stream_destroy(Stream* s) { delete s; return 0; }
+inline int set_device(int) { return 0; }
+inline const char* last_error_string() { return "emu"; }
+template <class K>
+inline int launch(Stream*, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
+  std::vector<unsigned char> lds(lds_bytes + 16);
+  int nph = K::nphases(p);
+  for (unsigned by = 0; by < gy; by++)
+    for (unsigned bx = 0; bx < gx; bx++)
+      for (int ph = 0; ph < nph; ph++)
+        for (int t = 0; t < threads; t++) K::phase(ph, p, (int)bx, (int)by, t, threads, lds.data());
+  return 0;
+}
+MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { if (v < *a) *a = v; }
+MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { if (v > *a) *a = v; }
+}  // namespace msrt
+MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+
+#else  // ---------------------------------------------------------------- HIP (gfx950)
+#include <hip/hip_runtime.h>
+#define MS_HD __host__ __device__ __forceinline__
+#define MS_DEV __device__ __forceinline__
+#define MS_RESTRICT __restrict__
+namespace msrt {
+typedef ihipStream_t Stream;
+inline int malloc_dev(void** p, size_t n) { return (int)hipMalloc(p, n ? n : 1); }
+inline int free_dev(void* p) { return (int)hipFree(p); }
+inline int malloc_host(void** p, size_t n) { return (int)hipHostMalloc(p, n ? n : 1, hipHostMallocDefault); }
+inline int free_host(void* p) { return (int)hipHostFree(p); }
+inline int h2d(void* d, const void* h, size_t n, Stream* s) { return (int)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); }
+inline int d2h(void* h, const void* d, size_t n, Stream* s) { return (int)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s); }
+inline int d2d(void* d, const void* s_, size_t n, Stream* s) { return (int)hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s); }
+inline int memset_dev(void* d, int v, size_t n, Stream* s) { return (int)hipMemsetAsync(d, v, n, s); }
+inline int sync(Stream* s) { return (int)hipStreamSynchronize(s); }
+inline int stream_create(Stream** s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+inline int stream_destroy(Stream* s) { return (int)hipStreamDestroy(s); }
+inline int set_device(int d) { return (int)hipSetDevice(d); }
+inline const char* last_error_string() { return hipGetErrorString(hipGetLastError()); }
+
+template <class K>
+__global__ void __launch_bounds__(K::THREADS) ms_kmain(const typename K::Params p) {
+  extern __shared__ __align__(16) unsigned char ms_lds[];
+  const int nph = K::nphases(p);
+  for (int ph = 0; ph < nph; ph++) {
+    K::phase(ph, p, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, K::THREADS, ms_lds);
+    if (ph + 1 < nph) __syncthreads();
+  }
+}
+template <class K>
+inline int launch(Stream* s, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
+  if (threads != K::THREADS) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(ms_kmain<K>), dim3(gx, gy, 1), dim3(threads, 1, 1), lds_bytes, s, p);
+  return (int)hipGetLastError();
+}
+MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { atomicMin(a, v); }
+MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { atomicMax(a, v); }
+}  // namespace msrt
+MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+#endif

@@ -1,0 +1,152 @@
+"""Parity cases shared by the CPU-emulation suite (tests/test_emu_parity.py) and
+the GPU suite (tests/test_gpu_parity.py): the C-ABI library (HIP build, or the
+emulation build of the same kernel code) against the CPU oracle on the same
+seeded inputs, bit-exact.  `mk(field)` returns a mini_stark_amd.Context."""
+import ctypes as C
+
+import numpy as np
+
+from common import MODULUS, EXT, SplitMix64, fibonacci_trace, fibonacci_trace_fast, fibonacci_closures
+from oracle import oracle as orc
+
+
+def rand_field(field, shape, seed):
+    rng = np.random.default_rng(seed)
+    p = MODULUS[field]
+    a = rng.integers(0, 2**63, shape, dtype=np.uint64)
+    b = rng.integers(0, 2, shape, dtype=np.uint64)
+    return ((a << np.uint64(1)) | b) % np.uint64(p)
+
+
+def case_ntt(mk, field, log_n, batch=2):
+    ctx = mk(field)
+    n = 1 << log_n
+    a = rand_field(field, (batch, n), seed=log_n)
+    rc, out = ctx.ntt(a)
+    assert rc == 0, ctx.last_error()
+    for i in range(batch):
+        assert (out[i] == orc.ntt(field, a[i])).all()
+    rc, inv = ctx.ntt(out, inverse=True)
+    assert rc == 0 and (inv == a).all()
+    rc, out2 = ctx.ntt(a, inverse=True)
+    assert rc == 0
+    assert (out2[0] == orc.intt(field, a[0])).all()
+
+
+def case_coset_lde(mk, field, log_n, blowup):
+    ctx = mk(field)
+    n = 1 << log_n
+    coeffs = rand_field(field, (3, n), seed=100 + log_n)
+    shift = int(rand_field(field, (1,), seed=5)[0]) or 3
+    rc, out = ctx.coset_lde(coeffs, shift, n * blowup)
+    assert rc == 0, ctx.last_error()
+    for i in range(3):
+        assert (out[i] == orc.coset_lde(field, coeffs[i], shift, n * blowup)).all()
+
+
+def case_merkle(mk, field, leaf_num, ext, lpn, ic, special=False):
+    ctx = mk(field)
+    leafs = rand_field(field, (leaf_num * ext,), seed=leaf_num + lpn)
+    if special:  # zeros, small values, p-1, digit-count boundaries
+        p = MODULUS[field]
+        vals = [0, 1, 9, 10, 99999, 100000, 10**9, 10**10 - 1, 10**10, p - 1, 10**19 % p, (10**19 - 1) % p, 2**32 % p, 12345678901234567890 % p]
+        for i, v in enumerate(vals):
+            leafs[i % leafs.size] = v % p
+    rc, nodes, root = ctx.merkle_commit(leafs, ext, lpn, ic)
+    orc_rc, onodes, oroot = orc.merkle_build(leafs, ext, lpn, ic)
+    assert (rc == 0) == (orc_rc == 0), (rc, orc_rc, ctx.last_error())
+    if rc == 0:
+        assert (nodes == onodes).all()
+        assert root == oroot
+
+
+def drive(sess, field, trace, blowup, nq_fri, seed, rounds=None, q_ood=2, read_big=True):
+    """Runs one full prove on `sess` (oracle Session or mini_stark_amd Context) with challenges
+    drawn from SplitMix64(seed); returns the list of stage outputs."""
+    p, e = MODULUS[field], EXT[field]
+    N, w = trace.shape
+    rng = SplitMix64(seed)
+    omega = orc.root_of_unity(field, N)
+    out = []
+    rc, root = sess.trace_commit(trace, 2 * w)
+    assert rc == 0
+    out.append(("trace_root", root))
+    assert sess.interpolate() == 0
+    for sc, idx in fibonacci_closures(field, N, omega):
+        assert sess.polys_lincomb(sc, idx) == 0
+    if read_big:
+        for i in range(sess.polys_count()):
+            out.append((f"poly{i}", sess.poly_read(i).tolist()))
+    shift = rng.nonzero(p)
+    rc, root = sess.lde_commit(blowup, shift, 2 * w)
+    assert rc == 0
+    out.append(("lde_root", root))
+    if read_big:
+        out.append(("lde", sess.lde_read().tolist()))
+    assert sess.mix(rng.field(p)) == 0
+    if read_big:
+        out.append(("validity", sess.validity_read().tolist()))
+    zs = np.array([[rng.field(p) for _ in range(e)] for _ in range(q_ood)], dtype=np.uint64)
+    rc, ev = sess.eval_ext(zs)
+    assert rc == 0
+    out.append(("ood", ev.tolist()))
+    if rounds is None:
+        rounds = int(orc.lib().or_ceil_log2_k(C.c_uint64((N - 1) * blowup + 1), C.c_uint64(2)))
+    rc, root = sess.fri_begin(blowup, rounds)
+    assert rc == 0
+    out.append(("fri_root0", root))
+    for i in range(1, rounds):
+        z = [rng.field(p) for _ in range(e)]
+        rc, B = sess.fri_deep(z)
+        assert rc == 0
+        out.append((f"B{i}", B.tolist()))
+        rc, root = sess.fri_fold_commit([rng.field(p) for _ in range(e)])
+        assert rc == 0
+        out.append((f"fri_root{i}", root))
+    for i in range(rounds):
+        out.append((f"round_info{i}", tuple(sess.fri_round_info(i))))
+        if read_big:
+            out.append((f"round_poly{i}", sess.fri_round_poly(i).tolist()))
+            out.append((f"round_cw{i}", sess.fri_round_codeword(i).tolist()))
+    betas = [rng.next() for _ in range(nq_fri)] + [3, 2 * N * blowup]
+    rc, proof = sess.fri_query(betas)
+    assert rc == 0
+    out.append(("fri_proof", proof))
+    return out
+
+
+def case_prove(mk, field, log_n, blowup, nq_fri=2, seed=77, read_big=True):
+    N = 1 << log_n
+    trace = fibonacci_trace_fast(field, N)
+    a = drive(mk(field), field, trace, blowup, nq_fri, seed, read_big=read_big)
+    b = drive(orc.Session(field), field, trace, blowup, nq_fri, seed, read_big=read_big)
+    assert len(a) == len(b)
+    for (ka, va), (kb, vb) in zip(a, b):
+        assert ka == kb
+        assert va == vb, f"stage output {ka} differs"
+
+
+def case_errors(mk, field):
+    ctx = mk(field, fresh=True)
+    import mini_stark_amd as ms
+    t = fibonacci_trace(field, 8)
+    assert ctx.interpolate() == ms.ERR_STATE
+    assert ctx.trace_commit(t[:6], 6)[0] == ms.ERR_SHAPE          # air.rs:23 length not a power of two
+    assert ctx.trace_commit(t, 5)[0] == ms.ERR_SHAPE              # merkle.rs:93-104 tree not full
+    bad = t.copy(); bad[0, 0] = MODULUS[field]
+    assert ctx.trace_commit(bad, 6)[0] == ms.ERR_ARG
+    assert ctx.trace_commit(t, 6)[0] == 0
+    assert ctx.mix(1) == ms.ERR_STATE
+    assert ctx.interpolate() == 0
+    assert ctx.lde_commit(3, 5, 3)[0] == ms.ERR_ARG               # blowup not a power of two
+    assert ctx.lde_commit(2, 0, 3)[0] == ms.ERR_ARG
+    assert ctx.lde_commit(2, 5, 5)[0] == ms.ERR_SHAPE
+    assert ctx.fri_begin(2, 3)[0] == ms.ERR_STATE
+    assert ctx.mix(3) == 0
+    assert ctx.fri_fold_commit([1] * ctx.e)[0] == ms.ERR_STATE
+    assert ctx.fri_begin(2, 4)[0] == 0
+    assert ctx.fri_query([1])[0] == ms.ERR_STATE                  # commit phase unfinished
+    assert ctx.merkle_commit(np.arange(3, dtype=np.uint64), 1, 2, 2)[0] == ms.ERR_SHAPE
+    assert ctx.merkle_commit(np.zeros(0, dtype=np.uint64), 1, 2, 2)[0] == ms.ERR_SHAPE
+    assert ctx.num_queries(1, 4, 128)[0] == ms.ERR_SHAPE          # starks.rs:341-346
+    assert ctx.num_queries(20, 4, 129) == (0, 1, 3) if field == 0 else True

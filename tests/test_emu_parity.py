@@ -1,0 +1,68 @@
+"""CPU suite: the kernel code of mini-stark_amd/csrc compiled for host emulation
+(tests/emu, -DMS_EMU: every kernel phase executed thread by thread) against the
+oracle.  Checks kernel and host-orchestration logic in this GPU-less container;
+the same cases run on the real HIP build in tests/test_gpu_parity.py (-m gpu)."""
+import os
+import subprocess
+
+import pytest
+
+import mini_stark_amd as ms
+import parity_cases as pc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu", "libministark_emu.so")
+
+
+@pytest.fixture(scope="module")
+def mk():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+    cache = {}
+
+    def make(field, fresh=False):
+        if fresh:
+            return ms.Context(field, lib_path=EMU)
+        if field not in cache:
+            cache[field] = ms.Context(field, lib_path=EMU)
+        return cache[field]
+    return make
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 7, 9, 10, 11, 13, 16])
+def test_ntt(mk, field, log_n):
+    pc.case_ntt(mk, field, log_n)
+
+
+def test_ntt_three_pass(mk):
+    pc.case_ntt(mk, 0, 19, batch=1)
+    pc.case_ntt(mk, 1, 19, batch=1)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("log_n,blowup", [(3, 2), (4, 8), (9, 4), (12, 8)])
+def test_coset_lde(mk, field, log_n, blowup):
+    pc.case_coset_lde(mk, field, log_n, blowup)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("leaf_num,ext,lpn,ic", [(16, 1, 2, 2), (16, 1, 4, 2), (16, 1, 4, 4), (16, 1, 16, 16), (2, 1, 2, 2), (3, 1, 2, 2),
+                                                 (4096, 1, 2, 2), (6144, 1, 6, 2), (24, 1, 6, 2), (1 << 13, 0, 2, 2), (64, 0, 2, 2)])
+def test_merkle(mk, field, leaf_num, ext, lpn, ic):
+    e = ext or pc.EXT[field]
+    pc.case_merkle(mk, field, leaf_num, e, lpn, ic, special=True)
+
+
+@pytest.mark.parametrize("field,log_n,blowup", [(0, 4, 2), (0, 3, 8), (0, 6, 8), (1, 3, 2), (1, 5, 4), (0, 10, 8), (1, 10, 8)])
+def test_prove(mk, field, log_n, blowup):
+    pc.case_prove(mk, field, log_n, blowup)
+
+
+def test_prove_multilevel_scan(mk):
+    # N = 2^13: round 1 has 4096 folded coefficients -> two scan blocks (multi-level suffix Horner)
+    pc.case_prove(mk, 0, 13, 2, read_big=False)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_error_codes(mk, field):
+    pc.case_errors(mk, field)
