@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py — STARK proofs/s on the BASELINE.json workload, one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete proof of the hot path (src/starks.rs:59-169 between
+"trace filled" and "StarkProof returned"): trace commit, INTT, coset LDE,
+LDE commit, mix, DEEP-ALI evaluations, FRI commit phase (all rounds) and FRI
+query phase, with the Fibonacci-AIR trace already resident in HBM and the FRI
+proof left resident in HBM (PCIe-inclusive rate: see DESIGN.md).  Workload at
+every N: BASELINE.json configs[1] — Fibonacci AIR, Goldilocks, 2^20 trace rows,
+blowup 8, 20 security bits — one independent proof per step per rank (weak
+scaling: the path partitions over proofs; no data-path collective).
+
+Rank 0 prints ONE JSON line.  Extra legs (rank 0, outside the timed region):
+  roofline     — per-kernel HIP-event timings on the launching stream for the
+                 NTT pass kernel vs its algorithmic bytes
+  cpu_baseline — the CPU oracle ("port") on a bounded sample, N == 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-rows", type=int, default=20, help="log2 of trace rows (BASELINE configs[1]: 20)")
+    ap.add_argument("--blowup", type=int, default=8)
+    ap.add_argument("--field", type=int, default=0, help="0 Goldilocks, 1 BabyBear")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log-rows", type=int, default=18)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import mini_stark_amd as ms
+    from mini_stark_amd.stark import Stark, StarkConfig, fibonacci_air
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    N = 1 << args.log_rows
+    steps = N - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
+    ctx = ms.Context(args.field, device=local_rank)  # raises if libministark.so / the GPU is missing
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_stream(stream.cuda_stream)
+    tt = fibonacci_air(ctx, steps, secret_b=2 + rank)
+    cfg = StarkConfig(ctx, 20, args.blowup, steps, tt.constrain_number())
+    stark = Stark(cfg)
+    d_trace = torch.from_numpy(tt.data.view(np.int64)).to(dev)  # resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    def step():
+        with torch.cuda.stream(stream):
+            return stark.prove(tt, trace_device_ptr=d_trace.data_ptr(), read_fri_proof=False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    proof = None
+    for _ in range(args.warmup):
+        proof = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        # every rank's final FRI root, gathered over RCCL (outside the timed region): proves all ranks finished
+        mine = torch.frombuffer(bytearray(proof.fri_roots[-1]), dtype=torch.uint8).to(dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+
+    out = {
+        "metric": "stark_proofs_per_s", "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64" if args.field == 0 else "u32", "data": "synthetic",
+        "config": {"workload": f"Fibonacci AIR, {'Goldilocks' if args.field == 0 else 'BabyBear+Fp4'}, 2^{args.log_rows} trace rows, blowup {args.blowup}, 20 security bits "
+                               f"(w=3, c=6, rounds={cfg.rounds}, ood_queries={cfg.constrain_queries}, fri_queries={cfg.fri_queries}); one independent proof per step per GPU",
+                   "parallelism": f"replicas x{world} (no data-path collective)"},
+    }
+
+    if rank == 0:
+        # ---- roofline leg: per-kernel HIP events on the launching stream, one extra (untimed) proof
+        buf = C.create_string_buffer(1 << 14)
+        ctx.check(ctx.L.ms_profile_begin(ctx.h))
+        step()
+        ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
+        prof = json.loads(buf.value.decode())
+        k = prof["ntt_pass"]
+        avg_ms = k["ms"] / max(1, k["launches"])
+        achieved = (k["alg_bytes"] / max(1, k["launches"])) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_ntt_pass.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"kernel": "msntt::PassKernel<GL>" if args.field == 0 else "msntt::PassKernel<BB>", "bound": "hbm",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "launches_per_proof": k["launches"], "avg_launch_ms": avg_ms, "alg_bytes_per_launch": k["alg_bytes"] / max(1, k["launches"])}
+        tot = sum(v["ms"] for v in prof.values()) or 1.0
+        out["kernel_ms_per_proof"] = {n: round(v["ms"], 4) for n, v in prof.items() if v["launches"]}
+        out["kernel_time_covered_frac"] = tot / ms_per_step
+        sha = prof["leaf_hash"]["ms"] + prof["inner_hash"]["ms"]
+        out["sha256_share_of_kernel_time"] = sha / tot
+
+        # ---- CPU baseline leg (N == 1): oracle "port", single thread, bounded sample
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import parity_cases as pc
+            from common import fibonacci_trace_fast
+            from oracle import oracle as orc
+            cl = min(args.cpu_log_rows, args.log_rows)
+            tr = fibonacci_trace_fast(args.field, 1 << cl)
+            c0 = time.perf_counter()
+            pc.drive(orc.Session(args.field), args.field, tr, args.blowup, max(0, cfg.fri_queries - 2), seed=1, q_ood=cfg.constrain_queries, read_big=False)
+            ct = time.perf_counter() - c0
+            scale = float(1 << (args.log_rows - cl))
+            out["cpu_baseline"] = {"value": 1.0 / (ct * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
+                                   "sample": f"one 2^{cl}-row proof of the same AIR on the oracle (oracle/ministark_oracle.cpp, 1 thread) took {ct:.2f} s; "
+                                             f"scaled linearly x{int(scale)} to 2^{args.log_rows} rows (optimistic for the CPU: ignores the log factor)"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,11 @@ int ms_coset_lde(ms_ctx* ctx, const uint64_t* coeffs, size_t ncoef, size_t batch
 /* device-resident benchmark entry: runs the LDE stage of the current session again
  * (no host copies); used by bench.py to time the NTT kernels in isolation. */
 int ms_bench_lde(ms_ctx* ctx, size_t blowup, uint64_t shift);
+/* measurement aid: between begin/end every kernel launch is bracketed by HIP events on the
+ * launching stream; end() writes a JSON object {kernel: {launches, ms, alg_bytes}} (build-defined,
+ * no reference counterpart). */
+int ms_profile_begin(ms_ctx* ctx);
+int ms_profile_end(ms_ctx* ctx, char* json_out, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@
 // Compiled with hipcc for gfx950 (libministark.so).  There is no CPU fallback.
 #include "../../include/ministark.h"
 
+#include <cstdio>
 #include <map>
 #include <string>
 #include <vector>
@@ -78,6 +79,8 @@ struct CtxBase {
   virtual int ntt(u64* data, size_t n, size_t batch, int inverse) = 0;
   virtual int coset_lde(const u64* coeffs, size_t ncoef, size_t batch, u64 shift, u64* out, size_t L) = 0;
   virtual int bench_lde(size_t blowup, u64 shift) = 0;
+  virtual int profile_begin() = 0;
+  virtual int profile_end(char* out, size_t cap) = 0;
 };
 
 #define CK(...) do { int _e = (__VA_ARGS__); if (_e) return this->fail_rt(_e, #__VA_ARGS__); } while (0)
@@ -95,6 +98,47 @@ template <class F> struct Ctx : CtxBase {
 
   int fail_rt(int e, const char* what) { err = std::string("runtime error ") + std::to_string(e) + " in " + what + ": " + msrt::last_error_string(); return MS_ERR_HIP; }
   int fail(int code, const char* msg) { err = msg; return code; }
+
+  // ---- optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
+  enum { K_NTT_PASS, K_SCALE_POW, K_LEAF_HASH, K_INNER_HASH, K_TRANSPOSE, K_IO, K_LINCOMB, K_MIX, K_EVAL, K_EVAL_REDUCE, K_FOLD,
+         K_SUFFIX_HORNER, K_DEGREE, K_FIND_FIRST, K_PATH, K_QUERY_POINTS, K_COUNT };
+  struct ProfRec { int kid; msrt::Event* a; msrt::Event* b; double bytes; };
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  double next_bytes = 0;  // algorithmic bytes attributed to the next launch
+  template <class K> int run(int kid, unsigned gx, unsigned gy, int threads, size_t lds, const typename K::Params& p) {
+    if (gx == 0 || gy == 0) return 0;
+    if (!prof_on) return msrt::launch<K>(stream, gx, gy, threads, lds, p);
+    ProfRec r; r.kid = kid; r.bytes = next_bytes; next_bytes = 0;
+    if (msrt::event_create(&r.a) || msrt::event_create(&r.b)) return 1;
+    msrt::event_record(r.a, stream);
+    int e = msrt::launch<K>(stream, gx, gy, threads, lds, p);
+    msrt::event_record(r.b, stream);
+    prof_recs.push_back(r);
+    return e;
+  }
+  int profile_begin() override { prof_on = true; return 0; }
+  int profile_end(char* out, size_t cap) override {
+    static const char* names[K_COUNT] = {"ntt_pass", "scale_pow", "leaf_hash", "inner_hash", "transpose_in", "io_copy", "lincomb", "mix", "eval", "eval_reduce",
+                                         "fold", "suffix_horner", "degree", "find_first", "merkle_path", "query_points"};
+    msrt::sync(stream);
+    double ms[K_COUNT] = {0}, by[K_COUNT] = {0}; unsigned long long cnt[K_COUNT] = {0};
+    for (auto& r : prof_recs) {
+      float t = 0.f; msrt::event_elapsed_ms(&t, r.a, r.b);
+      ms[r.kid] += t; by[r.kid] += r.bytes; cnt[r.kid]++;
+      msrt::event_destroy(r.a); msrt::event_destroy(r.b);
+    }
+    prof_recs.clear(); prof_on = false;
+    std::string j = "{";
+    for (int k = 0; k < K_COUNT; k++) {
+      char buf[256];
+      snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"alg_bytes\": %.0f}", k ? ", " : "", names[k], cnt[k], ms[k], by[k]);
+      j += buf;
+    }
+    j += "}";
+    if (out && cap) { size_t n = j.size() < cap - 1 ? j.size() : cap - 1; memcpy(out, j.data(), n); out[n] = 0; }
+    return 0;
+  }
 
   // ------------------------------------------------------------------ NTT plans
   struct Plan {
@@ -193,7 +237,8 @@ template <class F> struct Ctx : CtxBase {
       pp.first = (k == 0); pp.last = (k == P - 1);
       const size_t tiles = ((size_t)1 << cols_log) >> pp.log_C;
       const size_t lds = msntt::PassKernel<F>::lds_bytes(pp.log_r, pp.log_C);
-      CK(msrt::launch<msntt::PassKernel<F>>(stream, (unsigned)tiles, (unsigned)batch, msntt::THREADS, lds, pp));
+      next_bytes = (double)(n_in + n) * batch * sizeof(T) / P;  // (n_in + n)*s per transform, shared by its P passes
+      CK(run<msntt::PassKernel<F>>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, msntt::THREADS, lds, pp));
       in = out; in_bs = out_bs;
       log_Rp += pl->K[k];
     }
@@ -223,7 +268,8 @@ template <class F> struct Ctx : CtxBase {
     lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
     lp.width = width; lp.lpn = (u32)ts.lpn; lp.zero_as_empty = zae; lp.ngroups = ts.leaf_num / ts.lpn; lp.nodes = nodes.as<u32>();
     const size_t blocks = (lp.ngroups + msmerkle::THREADS - 1) / msmerkle::THREADS;
-    CK(msrt::launch<msmerkle::LeafHashKernel<F, EL>>(stream, (unsigned)blocks, 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
+    next_bytes = (double)lp.ngroups * (ts.lpn * EL * sizeof(T) + 32);
+    CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, (unsigned)blocks, 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
     size_t child_off = 0, nchildren = lp.ngroups;
     while (nchildren > 1) {
       msmerkle::InnerHashKernel::Params ip;
@@ -232,11 +278,13 @@ template <class F> struct Ctx : CtxBase {
       if (nparents <= 4 * (size_t)msmerkle::THREADS) {  // fused tree top: one workgroup walks the remaining levels
         u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ts.ic) nl++;
         ip.nlevels = nl;
-        CK(msrt::launch<msmerkle::InnerHashKernel>(stream, 1, 1, msmerkle::THREADS, 0, ip));
+        next_bytes = (double)nchildren * 32 * 2;
+        CK(run<msmerkle::InnerHashKernel>(K_INNER_HASH, 1, 1, msmerkle::THREADS, 0, ip));
         break;
       }
       ip.nlevels = 1;
-      CK(msrt::launch<msmerkle::InnerHashKernel>(stream, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
+      next_bytes = (double)nparents * (ts.ic * 32 + 32);
+      CK(run<msmerkle::InnerHashKernel>(K_INNER_HASH, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
       child_off += nchildren; nchildren = nparents;
     }
     return 0;
@@ -303,14 +351,14 @@ template <class F> struct Ctx : CtxBase {
     if (d_io.ensure(n * 8)) return fail(MS_ERR_NOMEM, "io staging");
     CK(msrt::h2d(d_io.p, host, n * 8, stream));
     typename mspoly::NarrowKernel<F>::Params p{d_io.as<u64>(), dst, n};
-    CK(msrt::launch<mspoly::NarrowKernel<F>>(stream, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    CK(run<mspoly::NarrowKernel<F>>(K_IO, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
     return 0;
   }
   int download_widen(const T* src, size_t n, size_t limb_stride, u32 e, u64* host) {
     if (n == 0) return 0;
     if (d_io.ensure(n * e * 8)) return fail(MS_ERR_NOMEM, "io staging");
     typename mspoly::WidenKernel<F>::Params p{src, d_io.as<u64>(), n, limb_stride, e};
-    CK(msrt::launch<mspoly::WidenKernel<F>>(stream, grid1(n * e, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    CK(run<mspoly::WidenKernel<F>>(K_IO, grid1(n * e, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
     CK(msrt::d2h(host, d_io.p, n * e * 8, stream));
     CK(msrt::sync(stream));
     return 0;
@@ -337,7 +385,7 @@ template <class F> struct Ctx : CtxBase {
     }
     RQ(ensure_polys(w + 1));
     typename mspoly::TransposeInKernel<F>::Params tp{dsrc, d_polys.as<T>(), N, w, N};
-    CK(msrt::launch<mspoly::TransposeInKernel<F>>(stream, grid1(N * w, mspoly::THREADS), 1, mspoly::THREADS, 0, tp));
+    CK(run<mspoly::TransposeInKernel<F>>(K_TRANSPOSE, grid1(N * w, mspoly::THREADS), 1, mspoly::THREADS, 0, tp));
     // element f of trace.get_data() = column f % w, row f / w of the column-major copy
     RQ((tree_build<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
     trace_ts = ts;
@@ -365,7 +413,7 @@ template <class F> struct Ctx : CtxBase {
       if (t0 > 0) { p.s[kk] = F::from_u64(1); p.idx[kk] = npolys; kk++; }  // accumulate onto the partial result
       for (int t = t0; t < k && kk < mspoly::MAX_TERMS; t++, kk++) { p.s[kk] = F::from_u64(s[t]); p.idx[kk] = idx[t]; }
       p.k = kk;
-      CK(msrt::launch<mspoly::LincombKernel<F>>(stream, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+      CK(run<mspoly::LincombKernel<F>>(K_LINCOMB, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
     }
     npolys++; have_lde = have_validity = false;
     return MS_OK;
@@ -396,7 +444,7 @@ template <class F> struct Ctx : CtxBase {
     sp.src = d_polys.as<T>(); sp.dst = d_coef.as<T>(); sp.src_bstride = N; sp.dst_bstride = N; sp.n = N;
     sp.s = F::from_u64(shift); sp.s_step = f_pow<F>(sp.s, msntt::ScalePowKernel<F>::THREADS);
     const int per_block = msntt::ScalePowKernel<F>::THREADS * msntt::ScalePowKernel<F>::ITEMS;
-    CK(msrt::launch<msntt::ScalePowKernel<F>>(stream, grid1(N, per_block), (unsigned)c, msntt::ScalePowKernel<F>::THREADS, 0, sp));
+    CK(run<msntt::ScalePowKernel<F>>(K_SCALE_POW, grid1(N, per_block), (unsigned)c, msntt::ScalePowKernel<F>::THREADS, 0, sp));
     RQ(ntt_run(ctz64(L_), false, d_coef.as<T>(), N, N, d_lde.as<T>(), L_, c));
     return 0;
   }
@@ -425,7 +473,7 @@ template <class F> struct Ctx : CtxBase {
     const size_t tot = L * lde_c;
     if (d_io.ensure(tot * 8)) return fail(MS_ERR_NOMEM, "io");
     typename mspoly::TransposeOutKernel<F>::Params p{d_lde.as<T>(), d_io.as<u64>(), L, lde_c, L};
-    CK(msrt::launch<mspoly::TransposeOutKernel<F>>(stream, grid1(tot, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    CK(run<mspoly::TransposeOutKernel<F>>(K_IO, grid1(tot, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
     CK(msrt::d2h(out, d_io.p, tot * 8, stream));
     CK(msrt::sync(stream));
     return MS_OK;
@@ -436,7 +484,7 @@ template <class F> struct Ctx : CtxBase {
     if (r >= F::P) return fail(MS_ERR_ARG, "r not canonical");
     RQ(ensure_polys(npolys + 1));
     typename mspoly::MixKernel<F>::Params p{d_polys.as<T>(), N, N, npolys, F::from_u64(r), d_polys.as<T>() + (size_t)npolys * N};
-    CK(msrt::launch<mspoly::MixKernel<F>>(stream, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    CK(run<mspoly::MixKernel<F>>(K_MIX, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
     have_validity = true; nrounds_done = 0;
     return MS_OK;
   }
@@ -458,9 +506,9 @@ template <class F> struct Ctx : CtxBase {
     p.base = base; p.poly_stride = poly_stride; p.limb_stride = limb_stride; p.kstride = kstride; p.npoly = npoly;
     for (int i = 0; i < mspoly::MAX_POLYS; i++) { p.off[i] = i < npoly ? off[i] : 0; p.count[i] = i < npoly ? count[i] : 0; }
     p.z = z; p.z_step = e_pow<F, E>(z, EK::THREADS); p.partials = d_partials.as<T>();
-    CK(msrt::launch<EK>(stream, (unsigned)nblocks, 1, EK::THREADS, EK::lds_bytes(), p));
+    CK(run<EK>(K_EVAL, (unsigned)nblocks, 1, EK::THREADS, EK::lds_bytes(), p));
     typename mspoly::ReducePartialsKernel<F>::Params rp{d_partials.as<T>(), nblocks, npoly * E, dst};
-    CK(msrt::launch<mspoly::ReducePartialsKernel<F>>(stream, 1, 1, mspoly::ReducePartialsKernel<F>::THREADS, 0, rp));
+    CK(run<mspoly::ReducePartialsKernel<F>>(K_EVAL_REDUCE, 1, 1, mspoly::ReducePartialsKernel<F>::THREADS, 0, rp));
     return 0;
   }
   static bool load_ext(const u64* v, XE* out) { for (int l = 0; l < E; l++) { if (v[l] >= F::P) return false; out->c[l] = F::from_u64(v[l]); } return true; }
@@ -509,7 +557,7 @@ template <class F> struct Ctx : CtxBase {
     CK(msrt::memset_dev(dres, 0, 8, stream));
     if (n) {
       typename mspoly::DegreeKernel<F, E>::Params dp{poly, limb_stride, n, dres};
-      CK(msrt::launch<mspoly::DegreeKernel<F, E>>(stream, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
+      CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
     }
     CK(msrt::d2h(pinned, dres, 8, stream));
     if (r) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, r->nodes.template as<u8>() + (r->ts.nodes - 1) * 32, 32, stream));
@@ -597,7 +645,7 @@ template <class F> struct Ctx : CtxBase {
       typename KT::Params p; fill(p, l);
       const size_t nb = (ms[l] + BS - 1) / BS;
       p.final_mode = 0; p.agg = base + aoff[l]; p.agg_limb_stride = nb;
-      CK(msrt::launch<KT>(stream, (unsigned)nb, 1, KT::THREADS, KT::lds_bytes(), p));
+      CK(run<KT>(K_SUFFIX_HORNER, (unsigned)nb, 1, KT::THREADS, KT::lds_bytes(), p));
     }
     for (int l = nl - 1; l >= 0; l--) {  // finals, top-down
       const size_t nb = (ms[l] + BS - 1) / BS;
@@ -610,13 +658,13 @@ template <class F> struct Ctx : CtxBase {
         const size_t nb_below = ms[l];  // == number of blocks at level l-1
         CK(msrt::memset_dev(base + coff[l - 1], 0, nb_below * E * sizeof(T), stream));
         p.out = base + coff[l - 1]; p.out_limb_stride = nb_below; p.out_off = 0; p.out_stride = 1;
-        CK(msrt::launch<KT>(stream, (unsigned)nb, 1, KT::THREADS, KT::lds_bytes(), p));
+        CK(run<KT>(K_SUFFIX_HORNER, (unsigned)nb, 1, KT::THREADS, KT::lds_bytes(), p));
       } else {
         typename KO::Params p; fill(p, l);
         p.final_mode = 1;
         if (has_carry) { p.carry = base + coff[l]; p.carry_limb_stride = nb; }
         p.out = out; p.out_limb_stride = out_limb_stride; p.out_off = out_off; p.out_stride = out_stride; p.h0 = h0;
-        CK(msrt::launch<KO>(stream, (unsigned)nb, 1, KO::THREADS, KO::lds_bytes(), p));
+        CK(run<KO>(K_SUFFIX_HORNER, (unsigned)nb, 1, KO::THREADS, KO::lds_bytes(), p));
       }
     }
     return 0;
@@ -637,7 +685,7 @@ template <class F> struct Ctx : CtxBase {
     size_t nq_coef = 0;
     if (m >= 2) {
       typename mspoly::FoldKernel<F, E>::Params fp{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a};  // fri.rs:361-372
-      CK(msrt::launch<mspoly::FoldKernel<F, E>>(stream, grid1(m, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
+      CK(run<mspoly::FoldKernel<F, E>>(K_FOLD, grid1(m, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
       // (folded - B(alpha)) / (x - z): quotient coefficients are H_1.. of the suffix Horner in z (fri.rs:99-101)
       RQ((suffix_horner<T>(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), nr->cap, 0, 1, nullptr)));
       nq_coef = m - 1;
@@ -744,14 +792,14 @@ template <class F> struct Ctx : CtxBase {
         RQ((eval_views<E>(cr->poly.template as<T>(), 0, cr->cap, 1, off1, cnt1, 1, X3, d_y3 + (size_t)j * E)));  // fri.rs:153
       }
       typename mspoly::QueryPointsKernel<F, E>::Params qp{d_h0e, d_h0o, d_y3, dt_x1 + i * nq, dt_x3 + i * nq, nq, blob, dt_rec + i * nq, d_tg};
-      CK(msrt::launch<mspoly::QueryPointsKernel<F, E>>(stream, grid1(nq, 64), 1, 64, 0, qp));
+      CK(run<mspoly::QueryPointsKernel<F, E>>(K_QUERY_POINTS, grid1(nq, 64), 1, 64, 0, qp));
       unsigned long long* didx = d_idx.as<unsigned long long>() + i * nq * 2;
       typename mspoly::FindFirstKernel<F, E>::Params ff{pr->cw.template as<T>(), pr->D, pr->D, d_tg, 2 * nq, didx};  // merkle.rs:216-225
-      CK(msrt::launch<mspoly::FindFirstKernel<F, E>>(stream, grid1(pr->D, mspoly::THREADS), 1, mspoly::THREADS, 0, ff));
+      CK(run<mspoly::FindFirstKernel<F, E>>(K_FIND_FIRST, grid1(pr->D, mspoly::THREADS), 1, mspoly::THREADS, 0, ff));
       typename msmerkle::PathKernel<F, E>::Params pk{pr->cw.template as<T>(), pr->D, pr->nodes.template as<u32>(), pr->D, 2, 2, (u32)(pr->ts.levels - 1), didx, (u32)(2 * nq), blob, dt_path + i * nq * 2};
       // the path kernel must not run for a value that was not found: checked after the loop via d_idx,
       // and PathKernel clamps nothing, so guard by launching it only after verifying on the host when D is tiny.
-      CK(msrt::launch<msmerkle::PathKernel<F, E>>(stream, grid1(2 * nq, 64), 1, 64, 0, pk));
+      CK(run<msmerkle::PathKernel<F, E>>(K_PATH, grid1(2 * nq, 64), 1, 64, 0, pk));
     }
     if (W * nq * 2 * 8 > pinned_cap) return fail(MS_ERR_ARG, "too many queries");
     CK(msrt::d2h(pinned, d_idx.p, W * nq * 2 * 8, stream));
@@ -816,7 +864,7 @@ template <class F> struct Ctx : CtxBase {
       sp.src = a.as<T>(); sp.dst = a.as<T>(); sp.src_bstride = ncoef; sp.dst_bstride = ncoef; sp.n = ncoef;
       sp.s = F::from_u64(shift); sp.s_step = f_pow<F>(sp.s, msntt::ScalePowKernel<F>::THREADS);
       const int per_block = msntt::ScalePowKernel<F>::THREADS * msntt::ScalePowKernel<F>::ITEMS;
-      int e = msrt::launch<msntt::ScalePowKernel<F>>(stream, grid1(ncoef, per_block), (unsigned)batch, msntt::ScalePowKernel<F>::THREADS, 0, sp);
+      int e = run<msntt::ScalePowKernel<F>>(K_SCALE_POW, grid1(ncoef, per_block), (unsigned)batch, msntt::ScalePowKernel<F>::THREADS, 0, sp);
       if (e) rc = fail_rt(e, "scale");
     }
     if (!rc) rc = ntt_run(ctz64(L_), false, a.as<T>(), ncoef, ncoef, b.as<T>(), L_, batch);
@@ -902,5 +950,7 @@ int ms_merkle_commit(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ex
 int ms_ntt(ms_ctx* ctx, uint64_t* data, size_t n, size_t batch, int inverse) { CTX_OR_FAIL; return B(ctx)->ntt(data, n, batch, inverse); }
 int ms_coset_lde(ms_ctx* ctx, const uint64_t* c, size_t ncoef, size_t batch, uint64_t shift, uint64_t* out, size_t L) { CTX_OR_FAIL; return B(ctx)->coset_lde(c, ncoef, batch, shift, out, L); }
 int ms_bench_lde(ms_ctx* ctx, size_t blowup, uint64_t shift) { CTX_OR_FAIL; return B(ctx)->bench_lde(blowup, shift); }
+int ms_profile_begin(ms_ctx* ctx) { CTX_OR_FAIL; return B(ctx)->profile_begin(); }
+int ms_profile_end(ms_ctx* ctx, char* json_out, size_t cap) { CTX_OR_FAIL; return B(ctx)->profile_end(json_out, cap); }
 
 }  // extern "C"

@@ -32,6 +32,11 @@ inline int stream_create(Stream** s) { *s = new Stream(); return 0; }
 inline int stream_destroy(Stream* s) { delete s; return 0; }
 inline int set_device(int) { return 0; }
 inline const char* last_error_string() { return "emu"; }
+struct Event { int dummy; };
+inline int event_create(Event** e) { *e = new Event(); return 0; }
+inline int event_destroy(Event* e) { delete e; return 0; }
+inline int event_record(Event*, Stream*) { return 0; }
+inline int event_elapsed_ms(float* ms, Event*, Event*) { *ms = 0.f; return 0; }
 template <class K>
 inline int launch(Stream*, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
   std::vector<unsigned char> lds(lds_bytes + 16);
@@ -67,6 +72,11 @@ inline int stream_create(Stream** s) { return (int)hipStreamCreateWithFlags(s, h
 inline int stream_destroy(Stream* s) { return (int)hipStreamDestroy(s); }
 inline int set_device(int d) { return (int)hipSetDevice(d); }
 inline const char* last_error_string() { return hipGetErrorString(hipGetLastError()); }
+typedef ihipEvent_t Event;
+inline int event_create(Event** e) { return (int)hipEventCreate(e); }
+inline int event_destroy(Event* e) { return (int)hipEventDestroy(e); }
+inline int event_record(Event* e, Stream* s) { return (int)hipEventRecord(e, s); }
+inline int event_elapsed_ms(float* ms, Event* a, Event* b) { return (int)hipEventElapsedTime(ms, a, b); }
 
 template <class K>
 __global__ void __launch_bounds__(K::THREADS) ms_kmain(const typename K::Params p) {

@@ -84,7 +84,7 @@ def test_full_size_properties(mk, field):
     rc, z = ctx.ntt(y, inverse=True)
     assert rc == 0 and (z == x).all()
     # linearity spot check of the forward transform: NTT(x)[0] = sum(x)
-    assert int(y[0, 0]) == int(sum(int(v) for v in x[0, ::1 << 10]) * 0 + (int(np.sum(x[0].astype(object))) % p))
+    assert int(y[0, 0]) == int(np.sum(x[0].astype(object))) % p
 
     N, blowup = 1 << 20, 8
     trace = fibonacci_trace_fast(field, N)
