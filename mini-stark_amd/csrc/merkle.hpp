@@ -70,43 +70,47 @@ struct Sha256 {
   }
 };
 
-// byte stream -> SHA-256, block buffer in LDS (word i of thread t at blk[i*nthreads + t])
-struct ShaStream {
+// byte stream -> SHA-256.  The message bytes are packed into big-endian words in a
+// per-thread ring of RW words that lives in LDS word-interleaved across the
+// workgroup (word i of thread t at ring[i*nthreads + t]: conflict free).
+// `put` never compresses; the owner calls `drain` after each element, so the
+// 64-round compression is instantiated exactly ONCE in the kernel (inlining it
+// at every put() site made the kernel I-cache bound).
+template <int RW> struct ShaStream {
+  static_assert((RW & (RW - 1)) == 0 && RW >= 32, "ring must be a power of two >= 2 blocks");
   Sha256 h;
-  u32* blk; int nthreads, tid;
-  u32 cur;      // bytes of the word being assembled (big-endian)
-  u32 nb;       // bytes in the current block
-  u64 total;
-  MS_HD void init(u32* lds_words, int nthreads_, int tid_) { h.init(); blk = lds_words; nthreads = nthreads_; tid = tid_; cur = 0; nb = 0; total = 0; }
-  MS_HD void flush_block() {
-    u32 w[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) w[i] = blk[i * nthreads + tid];
-    h.compress(w);
-    nb = 0;
-  }
+  u32* ring; int nthreads, tid;
+  u32 cur;     // last bytes appended (big-endian)
+  u32 total;   // bytes appended
+  u32 done;    // bytes compressed
+  MS_HD void init(u32* lds_words, int nthreads_, int tid_) { h.init(); ring = lds_words; nthreads = nthreads_; tid = tid_; cur = 0; total = 0; done = 0; }
   MS_HD void put(u32 ch) {
     cur = (cur << 8) | ch;
-    nb++; total++;
-    if ((nb & 3) == 0) {
-      blk[((nb >> 2) - 1) * nthreads + tid] = cur;
-      cur = 0;
-      if (nb == 64) flush_block();
+    total++;
+    if ((total & 3) == 0) ring[(((total >> 2) - 1) & (RW - 1)) * nthreads + tid] = cur;
+  }
+  MS_HD void drain() {
+    while (total - done >= 64) {
+      u32 w[16];
+      const u32 base = done >> 2;
+#pragma unroll
+      for (int i = 0; i < 16; i++) w[i] = ring[((base + i) & (RW - 1)) * nthreads + tid];
+      h.compress(w);
+      done += 64;
     }
   }
-  MS_HD void finish(u32 (&out)[8]) {
-    u64 bits = total * 8;
+  // FIPS 180-4 padding; caller drains afterwards
+  MS_HD void pad() {
+    const u64 bits = (u64)total * 8;
     put(0x80);
-    while (nb != 56) put(0);
+    while ((total & 63) != 56) put(0);
     for (int k = 7; k >= 0; k--) put((u32)(bits >> (8 * k)) & 0xff);
-    for (int k = 0; k < 8; k++) out[k] = h.st[k];
-    total = 0;
   }
 };
 
 // canonical decimal of a base element, most significant digit first, no
 // leading zeros; ZERO -> "" (zero_as_empty) or "0".
-template <class F> MS_HD void put_dec(ShaStream& s, typename F::T v_, int zero_as_empty) {
+template <class F, class S> MS_HD void put_dec(S& s, typename F::T v_, int zero_as_empty) {
   u64 v = F::to_u64(v_);
   if (v == 0) { if (!zero_as_empty) s.put('0'); return; }
   constexpr int ND = F::MAX_DIGITS;  // 20 (Goldilocks) / 10 (BabyBear)
@@ -137,7 +141,7 @@ template <class F> MS_HD void put_dec(ShaStream& s, typename F::T v_, int zero_a
   }
 }
 template <class F, int E> struct Display {
-  static MS_HD void put(ShaStream& s, const typename F::T* c, int zae) {
+  template <class S> static MS_HD void put(S& s, const typename F::T* c, int zae) {
     const char* a = "QuadExtField(";
     for (int i = 0; i < 13; i++) s.put((u32)a[i]);
     Display<F, E / 2>::put(s, c, zae);
@@ -147,7 +151,7 @@ template <class F, int E> struct Display {
   }
 };
 template <class F> struct Display<F, 1> {
-  static MS_HD void put(ShaStream& s, const typename F::T* c, int zae) { put_dec<F>(s, c[0], zae); }
+  template <class S> static MS_HD void put(S& s, const typename F::T* c, int zae) { put_dec<F>(s, c[0], zae); }
 };
 
 // Leaf-group hashing.  Element f of the committed vector lives at
@@ -163,26 +167,33 @@ template <class F, int E> struct LeafHashKernel {
     size_t ngroups;
     u32* nodes;  // 8 words per digest, standard byte order in memory
   };
+  // ring words: 63 leftover bytes + the longest element string must fit
+  static constexpr int ELEM_MAX = (E == 1) ? F::MAX_DIGITS : (E == 2 ? 21 + 2 * F::MAX_DIGITS : 63 + 4 * F::MAX_DIGITS);
+  static constexpr int RW = (63 + ELEM_MAX + 3) / 4 <= 32 ? 32 : 64;
   static MS_HD int nphases(const Params&) { return 1; }
-  static MS_HD size_t lds_bytes() { return (size_t)16 * THREADS * sizeof(u32); }
+  static MS_HD size_t lds_bytes() { return (size_t)RW * THREADS * sizeof(u32); }
   static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char* lds) {
     const size_t g = (size_t)bx * nthreads + tid;
     if (g >= p.ngroups) return;
-    ShaStream s; s.init(reinterpret_cast<u32*>(lds), nthreads, tid);
+    ShaStream<RW> s; s.init(reinterpret_cast<u32*>(lds), nthreads, tid);
     size_t f = g * p.lpn;
     size_t row = f / p.width; u32 col = (u32)(f - row * p.width);
-    for (u32 i = 0; i < p.lpn; i++) {
-      T c[E];
-      const T* ptr = p.base + (size_t)col * p.col_stride + row * p.row_stride;
+    for (u32 i = 0; i <= p.lpn; i++) {
+      if (i < p.lpn) {
+        T c[E];
+        const T* ptr = p.base + (size_t)col * p.col_stride + row * p.row_stride;
 #pragma unroll
-      for (int k = 0; k < E; k++) c[k] = ptr[(size_t)k * p.limb_stride];
-      Display<F, E>::put(s, c, p.zero_as_empty);
-      if (++col == p.width) { col = 0; row++; }
+        for (int k = 0; k < E; k++) c[k] = ptr[(size_t)k * p.limb_stride];
+        Display<F, E>::put(s, c, p.zero_as_empty);
+        if (++col == p.width) { col = 0; row++; }
+      } else {
+        s.pad();
+      }
+      s.drain();  // the only compression site
     }
-    u32 d[8]; s.finish(d);
     u32* out = p.nodes + g * 8;
 #pragma unroll
-    for (int k = 0; k < 8; k++) out[k] = bswap32(d[k]);
+    for (int k = 0; k < 8; k++) out[k] = bswap32(s.h.st[k]);
   }
 };
 
@@ -219,25 +230,26 @@ struct InnerHashKernel {
   }
 };
 
-// MerklePath extraction (src/merkle.rs:216-288) for `ntargets` leaf indices held
-// on the device.  Writes, per target, the serialised path
-//   u64 leaf_index | lpn*E u64 limbs | u64 nlevels | nlevels * ic * 32 bytes
-// at out + t*path_bytes.
+// MerklePath extraction (src/merkle.rs:216-288), one thread per opened leaf.  Each job names a
+// tree (FRI codeword view, width = 1) and the device word holding the leaf index; writes
+//   u64 leaf_index | lpn*E u64 limbs | u64 nlevels | nlevels * ic * 32 bytes      at out.
+template <class F, int E> struct PathJob {
+  const typename F::T* leafs; size_t limb_stride;
+  const u32* nodes; size_t leaf_num; u32 lpn, ic, nlevels /* levels-1 */;
+  const unsigned long long* idx;
+  unsigned char* out;
+};
 template <class F, int E> struct PathKernel {
   typedef typename F::T T;
   static constexpr int THREADS = 64;
-  struct Params {
-    const T* leafs; size_t limb_stride;   // FRI codeword view (width = 1)
-    const u32* nodes; size_t leaf_num; u32 lpn, ic, nlevels /* levels-1 */;
-    const unsigned long long* idx; u32 ntargets;
-    unsigned char* out; const size_t* out_off;  // byte offset per target
-  };
+  struct Params { const PathJob<F, E>* jobs; u32 njobs; };
   static MS_HD int nphases(const Params&) { return 1; }
-  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
+  static MS_DEV void phase(int, const Params& pp, int bx, int, int tid, int nthreads, unsigned char*) {
     const u32 t = (u32)bx * nthreads + tid;
-    if (t >= p.ntargets) return;
-    u64* o = reinterpret_cast<u64*>(p.out + p.out_off[t]);
-    const size_t li = (size_t)p.idx[t];
+    if (t >= pp.njobs) return;
+    const PathJob<F, E>& p = pp.jobs[t];
+    u64* o = reinterpret_cast<u64*>(p.out);
+    const size_t li = (size_t)*p.idx;
     if (li >= p.leaf_num) return;  // value not found: the host reports MS_ERR_LEAF_NOT_FOUND
     *o++ = li;
     const size_t start = li - li % p.lpn;  // merkle.rs:230-236

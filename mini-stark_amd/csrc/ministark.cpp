@@ -493,7 +493,7 @@ template <class F> struct Ctx : CtxBase {
     return download_widen(d_polys.as<T>() + (size_t)npolys * N, N, 0, 1, out);
   }
 
-  // evaluate `npoly` polynomials (views) at ext point z into d_small[out_slot .. ) as [npoly][E] T
+  // evaluate `npoly` polynomials (views) at ext point z into dst as [npoly][E] T
   template <int EC>
   int eval_views(const T* base, size_t poly_stride, size_t limb_stride, size_t kstride, const size_t* off, const size_t* count, int npoly, const XE& z, T* dst) {
     size_t maxc = 0;
@@ -501,14 +501,25 @@ template <class F> struct Ctx : CtxBase {
     typedef mspoly::EvalKernel<F, EC, E> EK;
     const size_t chunk = (size_t)EK::THREADS * EK::ITEMS;
     const size_t nblocks = maxc ? (maxc + chunk - 1) / chunk : 1;
-    if (d_partials.ensure(nblocks * npoly * E * sizeof(T))) return fail(MS_ERR_NOMEM, "partials");
+    if (nblocks > 1 && d_partials.ensure(nblocks * npoly * E * sizeof(T))) return fail(MS_ERR_NOMEM, "partials");
     typename EK::Params p;
     p.base = base; p.poly_stride = poly_stride; p.limb_stride = limb_stride; p.kstride = kstride; p.npoly = npoly;
     for (int i = 0; i < mspoly::MAX_POLYS; i++) { p.off[i] = i < npoly ? off[i] : 0; p.count[i] = i < npoly ? count[i] : 0; }
-    p.z = z; p.z_step = e_pow<F, E>(z, EK::THREADS); p.partials = d_partials.as<T>();
+    XE sq = z;
+    for (int i = 0; i < 9; i++) { p.zpow2[i] = sq; sq = e_mul<F>(sq, sq); }
+    p.partials = nblocks > 1 ? d_partials.as<T>() : dst;  // single block: P_0 is the value
     CK(run<EK>(K_EVAL, (unsigned)nblocks, 1, EK::THREADS, EK::lds_bytes(), p));
-    typename mspoly::ReducePartialsKernel<F>::Params rp{d_partials.as<T>(), nblocks, npoly * E, dst};
-    CK(run<mspoly::ReducePartialsKernel<F>>(K_EVAL_REDUCE, 1, 1, mspoly::ReducePartialsKernel<F>::THREADS, 0, rp));
+    if (nblocks > 1) {
+      typedef mspoly::ReducePartialsKernel<F, E> RK;
+      typename RK::Params rp;
+      rp.partials = d_partials.as<T>(); rp.nblocks = nblocks; rp.per_thread = (nblocks + RK::THREADS - 1) / RK::THREADS; rp.npoly = npoly; rp.out = dst;
+      XE zc = p.zpow2[8];  // z^256
+      for (int i = 256; i < (int)chunk; i *= 2) zc = e_mul<F>(zc, zc);  // z^CH
+      rp.zc = zc;
+      XE zs = e_pow<F, E>(zc, rp.per_thread);
+      for (int i = 0; i < 8; i++) { rp.zs2[i] = zs; zs = e_mul<F>(zs, zs); }
+      CK(run<RK>(K_EVAL_REDUCE, 1, 1, RK::THREADS, RK::lds_bytes(), rp));
+    }
     return 0;
   }
   static bool load_ext(const u64* v, XE* out) { for (int l = 0; l < E; l++) { if (v[l] >= F::P) return false; out->c[l] = F::from_u64(v[l]); } return true; }
@@ -607,66 +618,64 @@ template <class F> struct Ctx : CtxBase {
     return MS_OK;
   }
 
-  // multi-level suffix Horner: H_j of the view (m elements) with multiplier z.
-  // q_{j-1} = H_j goes to `out` (typed OutT), H_0 to h0 (may be null).
-  template <class OutT>
-  int suffix_horner(const T* in, size_t in_limb_stride, size_t in_off, size_t in_stride, size_t m, const XE& z,
-                    OutT* out, size_t out_limb_stride, size_t out_off, size_t out_stride, T* h0) {
-    if (m == 0) return 0;
+  // ---- suffix Horner job planning (shared by the DEEP quotient and the query quotients).
+  // A logical job (view, m, z, out, h0) expands into one kernel job per level; level buffers
+  // (aggregates = input of the level above, carries = output of the level above) come from d_sh.
+  typedef mspoly::SHJob<F, E> SHJ;
+  typedef mspoly::SuffixHornerKernel<F, E> SHK;
+  struct SHPlan { int nl; std::vector<SHJ> agg; std::vector<SHJ> fin; };  // agg[l] for l < nl-1, fin[l] for l < nl
+  static size_t sh_scratch_elems(size_t m) {
+    const size_t BS = mspoly::SH_BS;
+    size_t tot = 0, cur = m;
+    for (;;) { size_t nb = cur ? (cur + BS - 1) / BS : 1; tot += 2 * nb * E; if (nb <= 1) break; cur = nb; }
+    return tot;
+  }
+  // `scratch` must hold sh_scratch_elems(m) elements of T
+  SHPlan sh_plan(const T* in, size_t in_limb_stride, size_t in_off, size_t in_stride, size_t m, const XE& z,
+                 void* out, bool out_u64, size_t out_limb_stride, size_t out_off, size_t out_stride, T* h0, T* scratch) {
     const size_t BS = mspoly::SH_BS;
     std::vector<size_t> ms; ms.push_back(m);
-    while ((ms.back() + BS - 1) / BS > 1) ms.push_back((ms.back() + BS - 1) / BS);
+    while ((ms.back() ? (ms.back() + BS - 1) / BS : 1) > 1) ms.push_back((ms.back() + BS - 1) / BS);
     const int nl = (int)ms.size();
-    // level buffers: agg_l (input of level l+1) and carry_l, each E * nb_l
-    std::vector<size_t> aoff(nl), coff(nl);
+    std::vector<size_t> aoff(nl), coff(nl), nbs(nl);
     size_t tot = 0;
-    for (int l = 0; l < nl; l++) { size_t nb = (ms[l] + BS - 1) / BS; aoff[l] = tot; tot += nb * E; coff[l] = tot; tot += nb * E; }
-    if (d_sh.ensure(tot * sizeof(T))) return fail(MS_ERR_NOMEM, "scan levels");
-    T* base = d_sh.as<T>();
-    std::vector<XE> zl(nl); zl[0] = z;
-    std::vector<std::vector<XE>> zp(nl, std::vector<XE>(9));
+    for (int l = 0; l < nl; l++) { nbs[l] = ms[l] ? (ms[l] + BS - 1) / BS : 1; aoff[l] = tot; tot += nbs[l] * E; coff[l] = tot; tot += nbs[l] * E; }
+    SHPlan pl; pl.nl = nl; pl.agg.resize(nl > 1 ? nl - 1 : 0); pl.fin.resize(nl);
+    XE zl = z;
     for (int l = 0; l < nl; l++) {
-      XE s = e_pow<F, E>(zl[l], mspoly::SH_SEG);
-      for (int i = 0; i < 9; i++) { zp[l][i] = s; s = e_mul<F>(s, s); }
-      if (l + 1 < nl) zl[l + 1] = zp[l][8];  // z^(SEG*256) = z^BS
-    }
-    typedef mspoly::SuffixHornerKernel<F, E, T> KT;
-    typedef mspoly::SuffixHornerKernel<F, E, OutT> KO;
-    auto fill = [&](auto& p, int l) {
-      p.zs = nullptr; p.in_boff = p.out_boff = p.h0_boff = p.agg_boff = p.carry_boff = 0;
-      p.z = zl[l]; for (int i = 0; i < 9; i++) p.zpow[i] = zp[l][i];
-      p.m = ms[l];
-      if (l == 0) { p.in = in; p.in_limb_stride = in_limb_stride; p.in_off = in_off; p.in_stride = in_stride; }
-      else { p.in = base + aoff[l - 1]; p.in_limb_stride = (ms[l - 1] + BS - 1) / BS; p.in_off = 0; p.in_stride = 1; }
-      p.agg = nullptr; p.agg_limb_stride = 0; p.carry = nullptr; p.carry_limb_stride = 0;
-      p.out = nullptr; p.out_limb_stride = 0; p.out_off = 0; p.out_stride = 1; p.h0 = nullptr;
-    };
-    for (int l = 0; l + 1 < nl; l++) {  // aggregates, bottom-up
-      typename KT::Params p; fill(p, l);
-      const size_t nb = (ms[l] + BS - 1) / BS;
-      p.final_mode = 0; p.agg = base + aoff[l]; p.agg_limb_stride = nb;
-      CK(run<KT>(K_SUFFIX_HORNER, (unsigned)nb, 1, KT::THREADS, KT::lds_bytes(), p));
-    }
-    for (int l = nl - 1; l >= 0; l--) {  // finals, top-down
-      const size_t nb = (ms[l] + BS - 1) / BS;
-      const bool has_carry = (l + 1 < nl);
-      if (l > 0) {
-        typename KT::Params p; fill(p, l);
-        p.final_mode = 1;
-        if (has_carry) { p.carry = base + coff[l]; p.carry_limb_stride = nb; }
-        // this level's H_{b+1} is the carry-in of block b one level down
-        const size_t nb_below = ms[l];  // == number of blocks at level l-1
-        CK(msrt::memset_dev(base + coff[l - 1], 0, nb_below * E * sizeof(T), stream));
-        p.out = base + coff[l - 1]; p.out_limb_stride = nb_below; p.out_off = 0; p.out_stride = 1;
-        CK(run<KT>(K_SUFFIX_HORNER, (unsigned)nb, 1, KT::THREADS, KT::lds_bytes(), p));
-      } else {
-        typename KO::Params p; fill(p, l);
-        p.final_mode = 1;
-        if (has_carry) { p.carry = base + coff[l]; p.carry_limb_stride = nb; }
-        p.out = out; p.out_limb_stride = out_limb_stride; p.out_off = out_off; p.out_stride = out_stride; p.h0 = h0;
-        CK(run<KO>(K_SUFFIX_HORNER, (unsigned)nb, 1, KO::THREADS, KO::lds_bytes(), p));
+      SHJ j;
+      memset(&j, 0, sizeof j);
+      j.z = zl;
+      XE sq = e_pow<F, E>(zl, mspoly::SH_SEG);
+      for (int i = 0; i < 9; i++) { j.zpow[i] = sq; sq = e_mul<F>(sq, sq); }
+      zl = j.zpow[8];  // z^(SEG*256) = z^BS: multiplier of the level above
+      j.m = ms[l];
+      if (l == 0) { j.in = in; j.in_limb_stride = in_limb_stride; j.in_off = in_off; j.in_stride = in_stride; }
+      else { j.in = scratch + aoff[l - 1]; j.in_limb_stride = nbs[l - 1]; j.in_off = 0; j.in_stride = 1; }
+      if (l + 1 < nl) {  // aggregate job feeding level l+1
+        SHJ a = j; a.agg = scratch + aoff[l]; a.agg_limb_stride = nbs[l];
+        pl.agg[l] = a;
+        j.carry = scratch + coff[l]; j.carry_limb_stride = nbs[l];
       }
+      if (l == 0) { j.out = out; j.out_u64 = out_u64 ? 1 : 0; j.out_limb_stride = out_limb_stride; j.out_off = out_off; j.out_stride = out_stride; j.h0 = h0; }
+      else { j.out = scratch + coff[l - 1]; j.out_u64 = 0; j.out_limb_stride = nbs[l - 1]; j.out_off = 0; j.out_stride = 1; j.tail_zero = 1; }
+      pl.fin[l] = j;
     }
+    return pl;
+  }
+  int sh_launch_inline(const SHJ& j, int final_mode) {
+    typename SHK::Params p; p.jobs = nullptr; p.inline_job = j; p.final_mode = final_mode;
+    const size_t nb = j.m ? (j.m + mspoly::SH_BS - 1) / mspoly::SH_BS : 1;
+    CK(run<SHK>(K_SUFFIX_HORNER, (unsigned)nb, 1, SHK::THREADS, SHK::lds_bytes(), p));
+    return 0;
+  }
+  // one logical job, launched level by level with the job inline in the kernel arguments
+  int suffix_horner(const T* in, size_t in_limb_stride, size_t in_off, size_t in_stride, size_t m, const XE& z,
+                    T* out, size_t out_limb_stride, size_t out_off, size_t out_stride, T* h0) {
+    if (d_sh.ensure(sh_scratch_elems(m) * sizeof(T))) return fail(MS_ERR_NOMEM, "scan levels");
+    SHPlan pl = sh_plan(in, in_limb_stride, in_off, in_stride, m, z, out, false, out_limb_stride, out_off, out_stride, h0, d_sh.as<T>());
+    for (int l = 0; l + 1 < pl.nl; l++) RQ(sh_launch_inline(pl.agg[l], 0));
+    for (int l = pl.nl - 1; l >= 0; l--) RQ(sh_launch_inline(pl.fin[l], 1));
     return 0;
   }
 
@@ -687,7 +696,7 @@ template <class F> struct Ctx : CtxBase {
       typename mspoly::FoldKernel<F, E>::Params fp{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a};  // fri.rs:361-372
       CK(run<mspoly::FoldKernel<F, E>>(K_FOLD, grid1(m, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
       // (folded - B(alpha)) / (x - z): quotient coefficients are H_1.. of the suffix Horner in z (fri.rs:99-101)
-      RQ((suffix_horner<T>(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), nr->cap, 0, 1, nullptr)));
+      RQ(suffix_horner(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), nr->cap, 0, 1, nullptr));
       nq_coef = m - 1;
     }
     RQ(round_commit(nr, nq_coef));
@@ -713,12 +722,14 @@ template <class F> struct Ctx : CtxBase {
   }
 
   // ------------------------------------------------------------------ fri.rs:115-189
+  // The whole query phase is a fixed handful of batched launches, whatever the number of
+  // rounds and queries: every per-(window, query) step is a job in a device-side table.
   int fri_query(const u64* betas, int nq) override {
     if (nrounds_done != fri_rounds || fri_rounds == 0) return fail(MS_ERR_STATE, "fri_query before the commit phase finished");
     if (!betas || nq < 1) return fail(MS_ERR_ARG, "fri_query");
-    const size_t W = fri_rounds - 1;  // windows
+    const size_t W = fri_rounds - 1;  // windows (previous, round); round W is only evaluated
     // ---- layout of the MSFP blob
-    std::vector<size_t> rec_off(W * nq), path_off(W * nq * 2), qlen(W);
+    std::vector<size_t> rec_off(W * nq), path_off(W * nq * 2); std::vector<u64> qlen(W ? W : 1);
     size_t pos = 0;
     for (size_t i = 0; i < W; i++) {
       Round* pr = rounds[i];
@@ -733,79 +744,116 @@ template <class F> struct Ctx : CtxBase {
         path_off[(i * nq + j) * 2 + 1] = pos; pos += path_bytes;
       }
     }
-    if (d_blob.ensure(pos + 8)) return fail(MS_ERR_NOMEM, "proof blob");
     blob_size = 0;
-    // ---- per-window scalars and offset tables, one upload
-    const size_t n_off = W * nq * 3;
-    std::vector<u8> tab(n_off * sizeof(size_t) + W * nq * 2 * sizeof(T) + W * nq * 8);
-    size_t* t_rec = reinterpret_cast<size_t*>(tab.data());
-    size_t* t_path = t_rec + W * nq;
-    T* t_x1 = reinterpret_cast<T*>(tab.data() + n_off * sizeof(size_t));
-    T* t_x3 = t_x1 + W * nq;
-    u64* t_qlen = reinterpret_cast<u64*>(tab.data() + n_off * sizeof(size_t) + W * nq * 2 * sizeof(T));
-    std::vector<T> x3h(W * nq);
+    // ---- device buffers
+    size_t sh_elems = 0;
+    for (size_t i = 0; i <= W; i++) sh_elems += (size_t)nq * (sh_scratch_elems((rounds[i]->ncoef + 1) / 2) + sh_scratch_elems(rounds[i]->ncoef / 2));
+    const size_t n_h0 = (W + 1) * nq * 2 * E, n_tg = (W ? W : 1) * 2 * nq * E;
+    if (d_blob.ensure(pos + 8) || d_sh.ensure(sh_elems * sizeof(T)) || d_targets.ensure((n_h0 + n_tg) * sizeof(T)) || d_idx.ensure((W ? W : 1) * nq * 2 * 8))
+      return fail(MS_ERR_NOMEM, "query buffers");
+    u8* blob = d_blob.as<u8>();
+    T* d_h0 = d_targets.as<T>();
+    T* d_tg = d_h0 + n_h0;
+    unsigned long long* d_ix = d_idx.as<unsigned long long>();
+    // ---- suffix Horner jobs: (f - g)/((x-x1)(x-x2)) = Qe(x^2) + x Qo(x^2), Qe = (even(y) - even(x3))/(y - x3) and the
+    //      same for odd (fri.rs:159-167); the H_0 outputs are even(x3), odd(x3) (fri.rs:151-153)
+    std::vector<T> x1h((W + 1) * nq);
+    std::vector<std::vector<SHJ>> tables;  // launch order
+    std::vector<int> table_mode;
+    {
+      std::vector<SHPlan> plans;
+      T* scr = d_sh.as<T>();
+      for (size_t i = 0; i <= W; i++) {
+        Round* pr = rounds[i];
+        const T gp = f_root_of_unity<F>(ctz64(pr->D));
+        const size_t n = pr->ncoef, mm[2] = {(n + 1) / 2, n / 2};
+        for (int j = 0; j < nq; j++) {
+          u64 beta = betas[j];
+          if (i < W) { if (beta > pr->D) beta %= pr->D; }  // fri.rs:144-146 (quirk Q6: `>`)
+          else beta %= pr->D;                             // round.domain.element(beta) wraps (fri.rs:150)
+          const T x1 = f_pow<F>(gp, beta);                // fri.rs:148
+          x1h[i * nq + j] = x1;
+          const XE X3 = e_from_base<F, E>(F::mul(x1, x1));
+          for (int sgn = 0; sgn < 2; sgn++) {
+            void* out = nullptr;
+            if (i < W) out = blob + rec_off[i * nq + j] + (6 * E + 1) * 8;
+            plans.push_back(sh_plan(pr->poly.template as<T>(), pr->cap, sgn, 2, mm[sgn], X3, out, true, 1, (size_t)sgn * E, 2 * E,
+                                    d_h0 + ((i * nq + j) * 2 + sgn) * E, scr));
+            scr += sh_scratch_elems(mm[sgn]);
+          }
+        }
+      }
+      int max_nl = 1;
+      for (auto& pl : plans) if (pl.nl > max_nl) max_nl = pl.nl;
+      // group by level count so that every launch is homogeneous: aggregates bottom-up, finals top-down
+      for (int nl = 1; nl <= max_nl; nl++) {
+        for (int l = 0; l + 1 < nl; l++) { std::vector<SHJ> t; for (auto& pl : plans) if (pl.nl == nl) t.push_back(pl.agg[l]); if (!t.empty()) { tables.push_back(t); table_mode.push_back(0); } }
+        for (int l = nl - 1; l >= 0; l--) { std::vector<SHJ> t; for (auto& pl : plans) if (pl.nl == nl) t.push_back(pl.fin[l]); if (!t.empty()) { tables.push_back(t); table_mode.push_back(1); } }
+      }
+    }
+    // ---- find-first and path jobs
+    typedef mspoly::FindJob<F, E> FJ;
+    typedef msmerkle::PathJob<F, E> PJ;
+    std::vector<FJ> fjobs(W); std::vector<PJ> pjobs(W * nq * 2);
     for (size_t i = 0; i < W; i++) {
       Round* pr = rounds[i];
-      const T gp = f_root_of_unity<F>(ctz64(pr->D));
-      for (int j = 0; j < nq; j++) {
-        u64 beta = betas[j];
-        if (beta > pr->D) beta %= pr->D;  // fri.rs:144-146 (quirk Q6)
-        const T x1 = f_pow<F>(gp, beta);  // fri.rs:148
-        const T x3 = F::mul(x1, x1);      // fri.rs:150: round.domain.element(beta) == x1^2
-        t_rec[i * nq + j] = rec_off[i * nq + j];
-        t_path[(i * nq + j) * 2] = path_off[(i * nq + j) * 2];
-        t_path[(i * nq + j) * 2 + 1] = path_off[(i * nq + j) * 2 + 1];
-        t_x1[i * nq + j] = x1; t_x3[i * nq + j] = x3; x3h[i * nq + j] = x3;
-        t_qlen[i * nq + j] = qlen[i];
-      }
+      fjobs[i] = FJ{pr->cw.template as<T>(), pr->D, pr->D, d_tg + i * 2 * nq * E, 2 * nq, d_ix + i * 2 * nq};
+      for (int t = 0; t < 2 * nq; t++)
+        pjobs[i * 2 * nq + t] = PJ{pr->cw.template as<T>(), pr->D, pr->nodes.template as<u32>(), pr->D, 2, 2, (u32)(pr->ts.levels - 1), d_ix + i * 2 * nq + t,
+                                   blob + path_off[(i * nq + t / 2) * 2 + (t & 1)]};
     }
-    if (d_tabs.ensure(tab.size()) || d_targets.ensure((size_t)nq * (2 + 3) * E * sizeof(T)) || d_idx.ensure(W * nq * 2 * 8)) return fail(MS_ERR_NOMEM, "query tables");
+    // ---- one upload: [SH tables][find jobs][path jobs][rec_off][qlen][x1]
+    size_t bytes = 0;
+    std::vector<size_t> toff(tables.size());
+    for (size_t k = 0; k < tables.size(); k++) { toff[k] = bytes; bytes += tables[k].size() * sizeof(SHJ); }
+    const size_t off_f = bytes; bytes += fjobs.size() * sizeof(FJ);
+    const size_t off_p = bytes; bytes += pjobs.size() * sizeof(PJ);
+    const size_t off_rec = bytes; bytes += rec_off.size() * sizeof(size_t);
+    const size_t off_ql = bytes; bytes += qlen.size() * 8;
+    const size_t off_x1 = bytes; bytes += x1h.size() * sizeof(T);
+    std::vector<u8> tab(bytes + 8);
+    for (size_t k = 0; k < tables.size(); k++) memcpy(tab.data() + toff[k], tables[k].data(), tables[k].size() * sizeof(SHJ));
+    if (!fjobs.empty()) memcpy(tab.data() + off_f, fjobs.data(), fjobs.size() * sizeof(FJ));
+    if (!pjobs.empty()) memcpy(tab.data() + off_p, pjobs.data(), pjobs.size() * sizeof(PJ));
+    if (!rec_off.empty()) memcpy(tab.data() + off_rec, rec_off.data(), rec_off.size() * sizeof(size_t));
+    memcpy(tab.data() + off_ql, qlen.data(), qlen.size() * 8);
+    memcpy(tab.data() + off_x1, x1h.data(), x1h.size() * sizeof(T));
+    if (d_tabs.ensure(tab.size())) return fail(MS_ERR_NOMEM, "query tables");
     CK(msrt::h2d(d_tabs.p, tab.data(), tab.size(), stream));
     CK(msrt::sync(stream));  // `tab` is pageable host memory: keep it alive until the copy is done
-    const size_t* dt_rec = d_tabs.as<size_t>();
-    const size_t* dt_path = dt_rec + W * nq;
-    const T* dt_x1 = reinterpret_cast<const T*>(d_tabs.as<u8>() + n_off * sizeof(size_t));
-    const T* dt_x3 = dt_x1 + W * nq;
-    const u64* dt_qlen = reinterpret_cast<const u64*>(d_tabs.as<u8>() + n_off * sizeof(size_t) + W * nq * 2 * sizeof(T));
-    CK(msrt::memset_dev(d_idx.p, 0xFF, W * nq * 2 * 8, stream));
-    T* d_tg = d_targets.as<T>();            // [2nq][E] find-first targets
-    T* d_h0e = d_tg + (size_t)2 * nq * E;   // [nq][E]
-    T* d_h0o = d_h0e + (size_t)nq * E;
-    T* d_y3 = d_h0o + (size_t)nq * E;
-    u8* blob = d_blob.as<u8>();
-    for (size_t i = 0; i < W; i++) {
-      Round* pr = rounds[i]; Round* cr = rounds[i + 1];
-      const size_t n = pr->ncoef, me = (n + 1) / 2, mo = n / 2;
-      for (int j = 0; j < nq; j++) {
-        const XE X3 = e_from_base<F, E>(x3h[i * nq + j]);
-        u64* rec = reinterpret_cast<u64*>(blob + rec_off[i * nq + j]);
-        u64* qout = rec + 6 * E + 1;
-        // qlen word (fri.rs:167 `q.to_vec()` length)
-        CK(msrt::d2d(rec + 6 * E, dt_qlen + i * nq + j, 8, stream));
-        // (f - g)/((x-x1)(x-x2)) = Qe(x^2) + x Qo(x^2), Qe = (even(y)-even(x3))/(y-x3), same for odd (fri.rs:159-167);
-        // the suffix Horner also yields even(x3), odd(x3) as H_0
-        CK(msrt::memset_dev(d_h0e + (size_t)j * E, 0, E * sizeof(T), stream));
-        CK(msrt::memset_dev(d_h0o + (size_t)j * E, 0, E * sizeof(T), stream));
-        RQ((suffix_horner<u64>(pr->poly.template as<T>(), pr->cap, 0, 2, me, X3, qout, 1, 0, 2 * E, d_h0e + (size_t)j * E)));
-        RQ((suffix_horner<u64>(pr->poly.template as<T>(), pr->cap, 1, 2, mo, X3, qout, 1, E, 2 * E, d_h0o + (size_t)j * E)));
-        size_t off1[1] = {0}, cnt1[1] = {cr->ncoef};
-        RQ((eval_views<E>(cr->poly.template as<T>(), 0, cr->cap, 1, off1, cnt1, 1, X3, d_y3 + (size_t)j * E)));  // fri.rs:153
-      }
-      typename mspoly::QueryPointsKernel<F, E>::Params qp{d_h0e, d_h0o, d_y3, dt_x1 + i * nq, dt_x3 + i * nq, nq, blob, dt_rec + i * nq, d_tg};
-      CK(run<mspoly::QueryPointsKernel<F, E>>(K_QUERY_POINTS, grid1(nq, 64), 1, 64, 0, qp));
-      unsigned long long* didx = d_idx.as<unsigned long long>() + i * nq * 2;
-      typename mspoly::FindFirstKernel<F, E>::Params ff{pr->cw.template as<T>(), pr->D, pr->D, d_tg, 2 * nq, didx};  // merkle.rs:216-225
-      CK(run<mspoly::FindFirstKernel<F, E>>(K_FIND_FIRST, grid1(pr->D, mspoly::THREADS), 1, mspoly::THREADS, 0, ff));
-      typename msmerkle::PathKernel<F, E>::Params pk{pr->cw.template as<T>(), pr->D, pr->nodes.template as<u32>(), pr->D, 2, 2, (u32)(pr->ts.levels - 1), didx, (u32)(2 * nq), blob, dt_path + i * nq * 2};
-      // the path kernel must not run for a value that was not found: checked after the loop via d_idx,
-      // and PathKernel clamps nothing, so guard by launching it only after verifying on the host when D is tiny.
-      CK(run<msmerkle::PathKernel<F, E>>(K_PATH, grid1(2 * nq, 64), 1, 64, 0, pk));
+    const u8* dt = d_tabs.as<u8>();
+    // ---- launches
+    for (size_t k = 0; k < tables.size(); k++) {
+      size_t maxnb = 1;
+      for (auto& j : tables[k]) { size_t nb = j.m ? (j.m + mspoly::SH_BS - 1) / mspoly::SH_BS : 1; if (nb > maxnb) maxnb = nb; }
+      typename SHK::Params p; p.jobs = reinterpret_cast<const SHJ*>(dt + toff[k]); p.final_mode = table_mode[k];
+      memset(&p.inline_job, 0, sizeof p.inline_job);
+      CK(run<SHK>(K_SUFFIX_HORNER, (unsigned)maxnb, (unsigned)tables[k].size(), SHK::THREADS, SHK::lds_bytes(), p));
     }
-    if (W * nq * 2 * 8 > pinned_cap) return fail(MS_ERR_ARG, "too many queries");
-    CK(msrt::d2h(pinned, d_idx.p, W * nq * 2 * 8, stream));
-    CK(msrt::sync(stream));
-    const unsigned long long* hidx = reinterpret_cast<const unsigned long long*>(pinned);
-    for (size_t t = 0; t < W * nq * 2; t++) if (hidx[t] == ~0ULL) return fail(MS_ERR_LEAF_NOT_FOUND, "leaf is not included in the tree");
+    if (W) {
+      typename mspoly::QueryPointsKernel<F, E>::Params qp{d_h0, reinterpret_cast<const T*>(dt + off_x1), reinterpret_cast<const u64*>(dt + off_ql), (int)W, nq, blob,
+                                                         reinterpret_cast<const size_t*>(dt + off_rec), d_tg};
+      CK(run<mspoly::QueryPointsKernel<F, E>>(K_QUERY_POINTS, grid1(W * nq, 64), 1, 64, 0, qp));
+      CK(msrt::memset_dev(d_ix, 0xFF, W * nq * 2 * 8, stream));
+      // leaf lookup BY VALUE, first match (merkle.rs:216-225, quirk Q7): big codewords one launch each, the rest batched
+      size_t first_small = W;
+      for (size_t i = 0; i < W; i++) if (rounds[i]->D <= ((size_t)1 << 16)) { first_small = i; break; }
+      for (size_t i = 0; i < first_small; i++) {
+        typename mspoly::FindFirstKernel<F, E>::Params fp; fp.jobs = nullptr; fp.inline_job = fjobs[i];
+        CK(run<mspoly::FindFirstKernel<F, E>>(K_FIND_FIRST, grid1(rounds[i]->D, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
+      }
+      if (first_small < W) {
+        typename mspoly::FindFirstKernel<F, E>::Params fp; fp.jobs = reinterpret_cast<const FJ*>(dt + off_f) + first_small; fp.inline_job = fjobs[first_small];
+        CK(run<mspoly::FindFirstKernel<F, E>>(K_FIND_FIRST, grid1(rounds[first_small]->D, mspoly::THREADS), (unsigned)(W - first_small), mspoly::THREADS, 0, fp));
+      }
+      typename msmerkle::PathKernel<F, E>::Params pk{reinterpret_cast<const PJ*>(dt + off_p), (u32)pjobs.size()};
+      CK(run<msmerkle::PathKernel<F, E>>(K_PATH, grid1(pjobs.size(), 64), 1, 64, 0, pk));
+      if (W * nq * 2 * 8 > pinned_cap) return fail(MS_ERR_ARG, "too many queries");
+      CK(msrt::d2h(pinned, d_ix, W * nq * 2 * 8, stream));
+      CK(msrt::sync(stream));
+      const unsigned long long* hidx = reinterpret_cast<const unsigned long long*>(pinned);
+      for (size_t t = 0; t < W * nq * 2; t++) if (hidx[t] == ~0ULL) return fail(MS_ERR_LEAF_NOT_FOUND, "leaf is not included in the tree");
+    } else CK(msrt::sync(stream));
     blob_size = pos;
     return MS_OK;
   }

@@ -102,8 +102,11 @@ template <class F> struct MixKernel {
 // ---------------------------------------------------------------- Eval
 // Up to MAX_POLYS polynomials with EC-limb coefficients evaluated at one E-limb
 // point.  Coefficient k of poly i, limb l: base[i*poly_stride + l*limb_stride + off[i] + k*kstride].
-// Each workgroup reduces a chunk of THREADS*ITEMS coefficients to one partial
-// sum per polynomial; ReducePartials adds the partials.
+// Workgroup b owns coefficients [b*CH, (b+1)*CH), CH = THREADS*ITEMS: thread t accumulates
+// sum_j c[b*CH + t + j*THREADS] * z^(t + j*THREADS) (its z^t is a product of the host-supplied
+// z^(2^i), no per-thread exponentiation), the block sums the threads and writes the partial
+// P_b (WITHOUT the factor z^(b*CH)).  ReducePartials then forms sum_b P_b (z^CH)^b.
+// With a single block the result goes straight to `dst`.
 constexpr int MAX_POLYS = 8;
 template <class F, int EC, int E> struct EvalKernel {
   typedef typename F::T T;
@@ -112,7 +115,7 @@ template <class F, int EC, int E> struct EvalKernel {
   struct Params {
     const T* base; size_t poly_stride, limb_stride, kstride;
     size_t off[MAX_POLYS], count[MAX_POLYS]; int npoly;
-    Ext<F, E> z, z_step;  // z_step = z^THREADS
+    Ext<F, E> zpow2[9];   // z^(2^i), i <= 8  (zpow2[8] = z^THREADS)
     T* partials;          // [nblocks][npoly][E]
   };
   static MS_HD int nphases(const Params&) { return 2; }
@@ -128,18 +131,25 @@ template <class F, int EC, int E> struct EvalKernel {
       Ext<F, E> acc[MAX_POLYS];
       for (int i = 0; i < MAX_POLYS; i++) acc[i] = e_zero<F, E>();
       size_t k = (size_t)bx * (THREADS * ITEMS) + tid;
-      Ext<F, E> pw = e_pow<F, E>(p.z, k);
-      for (int it = 0; it < ITEMS; it++, k += THREADS) {
+      size_t kmax = 0;
+      for (int i = 0; i < MAX_POLYS; i++) if (i < p.npoly && p.count[i] > kmax) kmax = p.count[i];
+      if (k < kmax) {
+        Ext<F, E> pw = e_one<F, E>();
 #pragma unroll
-        for (int i = 0; i < MAX_POLYS; i++) {
-          if (i < p.npoly && k < p.count[i]) {
-            T c[EC];
-            const T* ptr = p.base + (size_t)i * p.poly_stride + p.off[i] + k * p.kstride;
-            for (int l = 0; l < EC; l++) c[l] = ptr[(size_t)l * p.limb_stride];
-            acc[i] = e_add<F, E>(acc[i], mul_coef(pw, c));
+        for (int i = 0; i < 8; i++) if ((tid >> i) & 1) pw = e_mul<F>(pw, p.zpow2[i]);
+        const Ext<F, E> zstep = p.zpow2[8];
+        for (int it = 0; it < ITEMS && k < kmax; it++, k += THREADS) {
+#pragma unroll
+          for (int i = 0; i < MAX_POLYS; i++) {
+            if (i < p.npoly && k < p.count[i]) {
+              T c[EC];
+              const T* ptr = p.base + (size_t)i * p.poly_stride + p.off[i] + k * p.kstride;
+              for (int l = 0; l < EC; l++) c[l] = ptr[(size_t)l * p.limb_stride];
+              acc[i] = e_add<F, E>(acc[i], mul_coef(pw, c));
+            }
           }
+          pw = e_mul<F>(pw, zstep);
         }
-        pw = e_mul<F>(pw, p.z_step);
       }
 #pragma unroll
       for (int i = 0; i < MAX_POLYS; i++)
@@ -147,23 +157,59 @@ template <class F, int EC, int E> struct EvalKernel {
           for (int l = 0; l < E; l++) red[(size_t)(i * E + l) * nthreads + tid] = acc[i].c[l];
       return;
     }
-    if (tid < p.npoly * E) {
+    // block sum: 4 lanes per output, then one lane adds the 4
+    const int width = p.npoly * E;
+    if (tid < width) {
       T s = 0;
       for (int t = 0; t < nthreads; t++) s = F::add(s, red[(size_t)tid * nthreads + t]);
-      p.partials[(size_t)bx * (p.npoly * E) + tid] = s;
+      p.partials[(size_t)bx * width + tid] = s;
     }
   }
 };
-template <class F> struct ReducePartialsKernel {
+// out[i] = sum_b partials[b][i] * zc^b,  i < npoly (E limbs each), zc = z^CH.
+// One workgroup: thread t runs Horner over its contiguous range of blocks, scales by
+// (zc^S)^t (bit product of zs2[i] = (zc^S)^(2^i)) and the block adds the threads.
+template <class F, int E> struct ReducePartialsKernel {
   typedef typename F::T T;
-  static constexpr int THREADS = 64;
-  struct Params { const T* partials; size_t nblocks; int width; T* out; };  // out[width]
-  static MS_HD int nphases(const Params&) { return 1; }
-  static MS_DEV void phase(int, const Params& p, int, int, int tid, int, unsigned char*) {
-    if (tid >= p.width) return;
-    T s = 0;
-    for (size_t b = 0; b < p.nblocks; b++) s = F::add(s, p.partials[b * p.width + tid]);
-    p.out[tid] = s;
+  static constexpr int THREADS = mspoly::THREADS;
+  struct Params { const T* partials; size_t nblocks, per_thread /* S */; int npoly; Ext<F, E> zc; Ext<F, E> zs2[8]; T* out; };
+  static MS_HD int nphases(const Params&) { return 2; }
+  static MS_HD size_t lds_bytes() { return (size_t)MAX_POLYS * E * THREADS * sizeof(T); }
+  static MS_DEV void phase(int ph, const Params& p, int, int, int tid, int nthreads, unsigned char* lds) {
+    T* red = reinterpret_cast<T*>(lds);
+    const int width = p.npoly * E;
+    if (ph == 0) {
+      const size_t b0 = (size_t)tid * p.per_thread;
+      Ext<F, E> acc[MAX_POLYS];
+      for (int i = 0; i < MAX_POLYS; i++) acc[i] = e_zero<F, E>();
+      if (b0 < p.nblocks) {
+        size_t b1 = b0 + p.per_thread; if (b1 > p.nblocks) b1 = p.nblocks;
+        for (size_t b = b1; b-- > b0;) {
+#pragma unroll
+          for (int i = 0; i < MAX_POLYS; i++) {
+            if (i < p.npoly) {
+              Ext<F, E> v; for (int l = 0; l < E; l++) v.c[l] = p.partials[b * width + i * E + l];
+              acc[i] = e_add<F, E>(e_mul<F>(acc[i], p.zc), v);
+            }
+          }
+        }
+        Ext<F, E> sc = e_one<F, E>();
+#pragma unroll
+        for (int i = 0; i < 8; i++) if ((tid >> i) & 1) sc = e_mul<F>(sc, p.zs2[i]);
+#pragma unroll
+        for (int i = 0; i < MAX_POLYS; i++) if (i < p.npoly) acc[i] = e_mul<F>(acc[i], sc);
+      }
+#pragma unroll
+      for (int i = 0; i < MAX_POLYS; i++)
+        if (i < p.npoly)
+          for (int l = 0; l < E; l++) red[(size_t)(i * E + l) * nthreads + tid] = acc[i].c[l];
+      return;
+    }
+    if (tid < width) {
+      T s = 0;
+      for (int t = 0; t < nthreads; t++) s = F::add(s, red[(size_t)tid * nthreads + t]);
+      p.out[tid] = s;
+    }
   }
 };
 
@@ -187,48 +233,53 @@ template <class F, int E> struct FoldKernel {
 };
 
 // ---------------------------------------------------------------- SuffixHorner
-// f_j (j < m): limb l at in[l*in_limb_stride + in_off + j*in_stride].
-// Block b owns [b*BS, (b+1)*BS), BS = THREADS*SEG.
+// A job describes one vector f_j (j < m): limb l at in[l*in_limb_stride + in_off + j*in_stride].
+// Block b of a job owns [b*BS, (b+1)*BS), BS = THREADS*SEG.  Jobs are batched over blockIdx.y
+// (a device table, or one job inline in the kernel arguments).
 //   mode AGG  : agg[l*agg_limb_stride + b] = sum_{k in block} f_k z^(k - b*BS)
 //   mode FINAL: with carry-in Hin_b = carry[l*carry_limb_stride + b] (carry == null: 0),
 //               writes H_j for j >= 1 to out[l*out_limb_stride + out_off + (j-1)*out_stride]
-//               (OutT = T or u64) and H_0 to h0[l].
+//               (u64 or T elements, out == null: discarded) and H_0 to h0[l];
+//               tail_zero: also stores 0 at out index m-1 (the output is the carry array of
+//               the level below, whose last block has no carry-in).
 // zpow[i] = z^(SEG * 2^i), i < 9.
 constexpr int SH_SEG = 8;
 constexpr int SH_BS = THREADS * SH_SEG;
-template <class F, int E, class OutT> struct SuffixHornerKernel {
+template <class F, int E> struct SHJob {
   typedef typename F::T T;
+  const T* in; size_t in_limb_stride, in_off, in_stride, m;
+  void* out; size_t out_limb_stride, out_off, out_stride;
+  T* h0;
+  T* agg; size_t agg_limb_stride;
+  const T* carry; size_t carry_limb_stride;
+  u32 out_u64, tail_zero;
+  Ext<F, E> z; Ext<F, E> zpow[9];
+};
+template <class F, int E> struct SuffixHornerKernel {
+  typedef typename F::T T;
+  typedef SHJob<F, E> Job;
   static constexpr int THREADS = mspoly::THREADS;
-  struct Params {
-    const T* in; size_t in_limb_stride, in_off, in_stride, m;
-    Ext<F, E> z; Ext<F, E> zpow[9];
-    int final_mode;
-    T* agg; size_t agg_limb_stride;
-    const T* carry; size_t carry_limb_stride;
-    OutT* out; size_t out_limb_stride, out_off, out_stride;
-    T* h0;
-    // batching over blockIdx.y: element offsets added per batch entry
-    size_t in_boff, out_boff, h0_boff, agg_boff, carry_boff;
-    const Ext<F, E>* zs;  // optional per-batch z / zpow table: zs[by*10 + 0] = z, [1..9] = zpow
-  };
+  struct Params { const Job* jobs; Job inline_job; int final_mode; };
   static MS_HD int nphases(const Params&) { return 2 + 9 + 2; }
   static MS_HD size_t lds_bytes() { return ((size_t)E * SH_BS + 2 * (size_t)E * (THREADS + 1)) * sizeof(T); }
   static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int nthreads, unsigned char* lds) {
+    const Job& jb = p.jobs ? p.jobs[by] : p.inline_job;
+    const size_t nb = jb.m ? (jb.m + SH_BS - 1) / SH_BS : 1;
+    if ((size_t)bx >= nb) return;
     T* fbuf = reinterpret_cast<T*>(lds);                 // [E][BS]
     T* sa = fbuf + (size_t)E * SH_BS;                    // [E][THREADS+1]  ping
     T* sb = sa + (size_t)E * (THREADS + 1);              // pong
     const size_t j0 = (size_t)bx * SH_BS;
-    const Ext<F, E> z = p.zs ? p.zs[(size_t)by * 10] : p.z;
     if (ph == 0) {  // coalesced load
-      const T* in = p.in + (size_t)by * p.in_boff;
       for (int i = tid; i < SH_BS; i += nthreads) {
         const size_t j = j0 + i;
         for (int l = 0; l < E; l++)
-          fbuf[(size_t)l * SH_BS + i] = (j < p.m) ? in[(size_t)l * p.in_limb_stride + p.in_off + j * p.in_stride] : (T)0;
+          fbuf[(size_t)l * SH_BS + i] = (j < jb.m) ? jb.in[(size_t)l * jb.in_limb_stride + jb.in_off + j * jb.in_stride] : (T)0;
       }
       return;
     }
     if (ph == 1) {  // per-thread segment aggregate a_t
+      const Ext<F, E> z = jb.z;
       Ext<F, E> a = e_zero<F, E>();
       for (int i = SH_SEG - 1; i >= 0; i--) {
         Ext<F, E> c; for (int l = 0; l < E; l++) c.c[l] = fbuf[(size_t)l * SH_BS + tid * SH_SEG + i];
@@ -238,7 +289,7 @@ template <class F, int E, class OutT> struct SuffixHornerKernel {
       if (tid == 0) {  // virtual element THREADS = carry-in
         for (int l = 0; l < E; l++) {
           T cv = 0;
-          if (p.final_mode && p.carry) cv = p.carry[(size_t)by * p.carry_boff + (size_t)l * p.carry_limb_stride + bx];
+          if (p.final_mode && jb.carry) cv = jb.carry[(size_t)l * jb.carry_limb_stride + bx];
           sa[(size_t)l * (THREADS + 1) + THREADS] = cv;
         }
       }
@@ -248,7 +299,7 @@ template <class F, int E, class OutT> struct SuffixHornerKernel {
       const int step = ph - 2, d = 1 << step;
       T* src = (step & 1) ? sb : sa;
       T* dst = (step & 1) ? sa : sb;
-      const Ext<F, E> zp = p.zs ? p.zs[(size_t)by * 10 + 1 + step] : p.zpow[step];
+      const Ext<F, E> zp = jb.zpow[step];
       for (int t = tid; t <= THREADS; t += nthreads) {
         Ext<F, E> v; for (int l = 0; l < E; l++) v.c[l] = src[(size_t)l * (THREADS + 1) + t];
         if (t + d <= THREADS) {
@@ -259,12 +310,13 @@ template <class F, int E, class OutT> struct SuffixHornerKernel {
       }
       return;
     }
-    T* sc = sb;  // 9 steps: last write went to sb (step 8 is even -> dst = sb)
+    T* sc = sb;  // 9 steps: the last one (step 8, even) wrote sb
     if (ph == 2 + 9) {
       if (!p.final_mode) {
-        if (tid == 0) for (int l = 0; l < E; l++) p.agg[(size_t)by * p.agg_boff + (size_t)l * p.agg_limb_stride + bx] = sc[(size_t)l * (THREADS + 1)];
+        if (tid == 0) for (int l = 0; l < E; l++) jb.agg[(size_t)l * jb.agg_limb_stride + bx] = sc[(size_t)l * (THREADS + 1)];
         return;
       }
+      const Ext<F, E> z = jb.z;
       Ext<F, E> h; for (int l = 0; l < E; l++) h.c[l] = sc[(size_t)l * (THREADS + 1) + tid + 1];
       for (int i = SH_SEG - 1; i >= 0; i--) {
         Ext<F, E> c; for (int l = 0; l < E; l++) c.c[l] = fbuf[(size_t)l * SH_BS + tid * SH_SEG + i];
@@ -274,14 +326,22 @@ template <class F, int E, class OutT> struct SuffixHornerKernel {
       return;
     }
     if (!p.final_mode) return;
-    OutT* out = p.out + (size_t)by * p.out_boff;
     for (int i = tid; i < SH_BS; i += nthreads) {
       const size_t j = j0 + i;
-      if (j >= p.m) continue;
+      if (j >= jb.m && !(j == 0)) continue;
       for (int l = 0; l < E; l++) {
         const T v = fbuf[(size_t)l * SH_BS + i];
-        if (j == 0) { if (p.h0) p.h0[(size_t)by * p.h0_boff + l] = v; }
-        else out[(size_t)l * p.out_limb_stride + p.out_off + (j - 1) * p.out_stride] = (OutT)F::to_u64(v);
+        if (j == 0) { if (jb.h0) jb.h0[l] = v; }
+        else if (jb.out) {
+          const size_t o = (size_t)l * jb.out_limb_stride + jb.out_off + (j - 1) * jb.out_stride;
+          if (jb.out_u64) reinterpret_cast<u64*>(jb.out)[o] = F::to_u64(v); else reinterpret_cast<T*>(jb.out)[o] = v;
+        }
+      }
+      if (jb.tail_zero && jb.out && j + 1 == jb.m) {
+        for (int l = 0; l < E; l++) {
+          const size_t o = (size_t)l * jb.out_limb_stride + jb.out_off + j * jb.out_stride;
+          if (jb.out_u64) reinterpret_cast<u64*>(jb.out)[o] = 0; else reinterpret_cast<T*>(jb.out)[o] = 0;
+        }
       }
     }
   }
@@ -302,13 +362,19 @@ template <class F, int E> struct DegreeKernel {
     if (nz) msrt::atomic_max_u64(p.result, (unsigned long long)(j + 1));
   }
 };
-// result[t] = min index j with leaf_j == target_t (caller fills result with ~0)
+// per window: result[t] = min index j with leaf_j == target_t (caller fills result with ~0).
+// Jobs batched over blockIdx.y (device table) or one inline job.
+template <class F, int E> struct FindJob {
+  const typename F::T* src; size_t limb_stride, n;
+  const typename F::T* targets /* [nt][E] */; int nt; unsigned long long* result;
+};
 template <class F, int E> struct FindFirstKernel {
   typedef typename F::T T;
   static constexpr int THREADS = mspoly::THREADS;
-  struct Params { const T* src; size_t limb_stride, n; const T* targets /* [nt][E] */; int nt; unsigned long long* result; };
+  struct Params { const FindJob<F, E>* jobs; FindJob<F, E> inline_job; };
   static MS_HD int nphases(const Params&) { return 1; }
-  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
+  static MS_DEV void phase(int, const Params& pp, int bx, int by, int tid, int nthreads, unsigned char*) {
+    const FindJob<F, E>& p = pp.jobs ? pp.jobs[by] : pp.inline_job;
     const size_t j = (size_t)bx * nthreads + tid;
     if (j >= p.n) return;
     T v[E];
@@ -322,28 +388,37 @@ template <class F, int E> struct FindFirstKernel {
 };
 
 // ---------------------------------------------------------------- query points
-// Per query t (fri.rs:148-154): from Ee = even(x3), Eo = odd(x3) (h0 buffers), x1 and y3:
-//   y1 = Ee + x1*Eo, y2 = Ee - x1*Eo; writes x1 y1 x2 y2 x3 y3 (E u64 limbs each) to the
-//   proof blob and (y1, y2) to the find-first target list.
+// One thread per (window i, query j) (fri.rs:148-154).  h0[(i*nq + j)*2 + s] holds even(x3) (s=0) /
+// odd(x3) (s=1) of round i's polynomial at x3 = x1^2 — the H_0 outputs of the suffix Horner runs;
+// window W (the last round) is only evaluated.  y1 = Ee + x1*Eo, y2 = Ee - x1*Eo and
+// y3 = p_{i+1}(x3) = Ee' + x1'*Eo' with x1' = x3 (the next window's y1).
+// Writes x1 y1 x2 y2 x3 y3 | qlen into the proof blob and (y1, y2) to the find-first targets.
 template <class F, int E> struct QueryPointsKernel {
   typedef typename F::T T;
   static constexpr int THREADS = 64;
   struct Params {
-    const T* h0e; const T* h0o; const T* y3;   // [nq][E] each
-    const T* x1; const T* x3;                   // [nq] base elements
-    int nq;
-    unsigned char* blob; const size_t* blob_off;  // byte offset of the points record per query
-    T* targets;                                    // [2*nq][E]
+    const T* h0;            // [(W+1)*nq*2][E]
+    const T* x1;            // [(W+1)*nq] base elements
+    const u64* qlen;        // [W]
+    int W, nq;
+    unsigned char* blob; const size_t* rec_off;  // [W*nq] byte offset of the record
+    T* targets;             // [W][2*nq][E]
   };
   static MS_HD int nphases(const Params&) { return 1; }
-  static MS_DEV void phase(int, const Params& p, int, int, int tid, int, unsigned char*) {
-    if (tid >= p.nq) return;
-    Ext<F, E> ee, eo, y3;
-    for (int l = 0; l < E; l++) { ee.c[l] = p.h0e[tid * E + l]; eo.c[l] = p.h0o[tid * E + l]; y3.c[l] = p.y3[tid * E + l]; }
-    const T x1 = p.x1[tid], x3 = p.x3[tid];
-    Ext<F, E> t = e_mul_base<F, E>(eo, x1);
-    Ext<F, E> y1 = e_add<F, E>(ee, t), y2 = e_sub<F, E>(ee, t);
-    u64* o = reinterpret_cast<u64*>(p.blob + p.blob_off[tid]);
+  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
+    const int t = bx * nthreads + tid;
+    if (t >= p.W * p.nq) return;
+    const int i = t / p.nq, j = t - i * p.nq;
+    Ext<F, E> ee, eo, ne, no;
+    for (int l = 0; l < E; l++) {
+      ee.c[l] = p.h0[((size_t)t * 2) * E + l]; eo.c[l] = p.h0[((size_t)t * 2 + 1) * E + l];
+      ne.c[l] = p.h0[((size_t)(t + p.nq) * 2) * E + l]; no.c[l] = p.h0[((size_t)(t + p.nq) * 2 + 1) * E + l];
+    }
+    const T x1 = p.x1[t], x3 = p.x1[t + p.nq];
+    Ext<F, E> d = e_mul_base<F, E>(eo, x1);
+    Ext<F, E> y1 = e_add<F, E>(ee, d), y2 = e_sub<F, E>(ee, d);
+    Ext<F, E> y3 = e_add<F, E>(ne, e_mul_base<F, E>(no, x3));
+    u64* o = reinterpret_cast<u64*>(p.blob + p.rec_off[t]);
     Ext<F, E> X1 = e_from_base<F, E>(x1), X2 = e_from_base<F, E>(F::neg(x1)), X3 = e_from_base<F, E>(x3);
     for (int l = 0; l < E; l++) o[l] = F::to_u64(X1.c[l]);
     for (int l = 0; l < E; l++) o[E + l] = F::to_u64(y1.c[l]);
@@ -351,7 +426,9 @@ template <class F, int E> struct QueryPointsKernel {
     for (int l = 0; l < E; l++) o[3 * E + l] = F::to_u64(y2.c[l]);
     for (int l = 0; l < E; l++) o[4 * E + l] = F::to_u64(X3.c[l]);
     for (int l = 0; l < E; l++) o[5 * E + l] = F::to_u64(y3.c[l]);
-    for (int l = 0; l < E; l++) { p.targets[(2 * tid) * E + l] = y1.c[l]; p.targets[(2 * tid + 1) * E + l] = y2.c[l]; }
+    o[6 * E] = p.qlen[i];
+    T* tg = p.targets + ((size_t)i * 2 * p.nq + 2 * j) * E;
+    for (int l = 0; l < E; l++) { tg[l] = y1.c[l]; tg[E + l] = y2.c[l]; }
   }
 };
 
