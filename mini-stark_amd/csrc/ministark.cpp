@@ -5,6 +5,7 @@
 #include "../../include/ministark.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -142,15 +143,18 @@ template <class F> struct Ctx : CtxBase {
 
   // ------------------------------------------------------------------ NTT plans
   struct Plan {
-    int log_n = 0, npass = 0, K[4] = {0, 0, 0, 0}, lo_bits = 0;
-    DevBuf tw_lo, tw_hi, w_r[4];
+    int log_n = 0, log_r0 = 0, log_rho = 0, npass = 0, K[4] = {0, 0, 0, 0}, lo_bits = 0;
+    DevBuf tw_lo, tw_hi, w_r[4], vtw, w0;
     T n_inv = 0;
   };
-  std::map<int, Plan*> plans;  // key = log_n*2 + inverse
+  std::map<int, Plan*> plans;  // key = (log_n*4 + log_pad)*2 + inverse
   DevBuf ntt_scratch;
+  int ntt_kmax = 9;            // largest tile (log2 rows) of a multi-pass plan; MS_NTT_KMAX overrides (tuning)
+  int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
 
-  int get_plan(int log_n, bool inverse, Plan** out) {
-    int key = log_n * 2 + (inverse ? 1 : 0);
+  // log_pad: the input is zero beyond n >> log_pad
+  int get_plan(int log_n, int log_pad, bool inverse, Plan** out) {
+    int key = (log_n * 4 + log_pad) * 2 + (inverse ? 1 : 0);
     auto it = plans.find(key);
     if (it != plans.end()) { *out = it->second; return 0; }
     if (log_n > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "domain larger than the field's two-adicity");
@@ -158,10 +162,23 @@ template <class F> struct Ctx : CtxBase {
     pl->log_n = log_n;
     if (log_n <= msntt::MAX_LOG_R) { pl->npass = 1; pl->K[0] = log_n; }
     else {
-      int P = (log_n + 8) / 9;
+      // virtual first pass: radix 2^log_pad of pure zero padding times a real radix 2^log_rho (<= 4) over the
+      // non-zero blocks; pick the smallest log_rho that minimises the number of real passes
+      int best_rho = 0, bestP = 1 << 20;
+      for (int lr = 0; lr <= (log_pad ? ntt_maxrho : 0); lr++) {
+        const int m = log_n - log_pad - lr;
+        if (m < 2) break;
+        int P = (m + ntt_kmax - 1) / ntt_kmax;
+        if (P < 2 && log_pad == 0) P = 2;
+        if (P < 1) P = 1;
+        if (P < bestP) { bestP = P; best_rho = lr; }
+      }
+      pl->log_rho = best_rho; pl->log_r0 = log_pad + best_rho;
+      const int m = log_n - pl->log_r0, P = bestP;
       pl->npass = P;
-      for (int i = 0; i < P; i++) pl->K[i] = log_n / P + (i < log_n % P ? 1 : 0);
+      for (int i = 0; i < P; i++) pl->K[i] = m / P + (i < m % P ? 1 : 0);
     }
+    const int log_r0 = pl->log_r0;
     T w = f_root_of_unity<F>(log_n);
     if (inverse) w = f_inv<F>(w);
     const size_t n = (size_t)1 << log_n;
@@ -189,9 +206,40 @@ template <class F> struct Ctx : CtxBase {
       CK(msrt::h2d(pl->w_r[i].p, tab.data(), r * sizeof(T), stream));
       CK(msrt::sync(stream));
     }
+    if (pl->log_r0) {  // w_r0^j
+      const size_t cnt = (size_t)1 << log_r0;
+      T wv = f_root_of_unity<F>(log_r0);
+      if (inverse) wv = f_inv<F>(wv);
+      std::vector<T> tab(cnt);
+      x = F::from_u64(1);
+      for (size_t j = 0; j < cnt; j++) { tab[j] = x; x = F::mul(x, wv); }
+      if (pl->w0.ensure(cnt * sizeof(T))) { delete pl; return fail(MS_ERR_NOMEM, "w0 table"); }
+      CK(msrt::h2d(pl->w0.p, tab.data(), cnt * sizeof(T), stream));
+      CK(msrt::sync(stream));
+    }
+    if (pl->log_r0) {  // w_(r0 r)^j for the virtual first pass folded into real pass 0
+      const int lg = pl->log_r0 + pl->K[0];
+      const size_t cnt = (size_t)1 << lg;
+      T wv = f_root_of_unity<F>(lg);
+      if (inverse) wv = f_inv<F>(wv);
+      std::vector<T> tab(cnt);
+      x = F::from_u64(1);
+      for (size_t j = 0; j < cnt; j++) { tab[j] = x; x = F::mul(x, wv); }
+      if (pl->vtw.ensure(cnt * sizeof(T))) { delete pl; return fail(MS_ERR_NOMEM, "vtw table"); }
+      CK(msrt::h2d(pl->vtw.p, tab.data(), cnt * sizeof(T), stream));
+      CK(msrt::sync(stream));
+    }
     plans[key] = pl;
     *out = pl;
     return 0;
+  }
+
+  template <bool INV>
+  int launch_pass(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
+    const size_t lds = msntt::PassKernel<F, INV, 256>::lds_bytes(pp.log_r, pp.log_C, pp.log_Rp, pp.last != 0);
+    if (ntt_th512 && pp.log_r >= 9 && pp.log_C == msntt::TILE_LOG_C)  // 8192-element tiles: 16 elements per thread
+      return run<msntt::PassKernel<F, INV, 512>>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, 512, lds, pp);
+    return run<msntt::PassKernel<F, INV, 256>>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, 256, lds, pp);
   }
 
   // batch transforms of size 2^log_n: src (n_in valid elements per entry, zero padded) -> dst
@@ -205,8 +253,12 @@ template <class F> struct Ctx : CtxBase {
       }
       return 0;
     }
+    // zero padding: n_in <= n >> log_pad  (log_pad <= 3)
+    int log_pad = 0;
+    while (log_pad < ntt_maxpad && (n_in << (log_pad + 1)) <= n) log_pad++;
     Plan* pl;
-    RQ(get_plan(log_n, inverse, &pl));
+    RQ(get_plan(log_n, log_pad, inverse, &pl));
+    const int log_r0 = pl->log_r0;
     const int P = pl->npass;
     const bool aliased = ((const void*)src == (const void*)dst);
     T* scr = nullptr;
@@ -217,7 +269,7 @@ template <class F> struct Ctx : CtxBase {
       scr = ntt_scratch.as<T>();
     }
     const T* in = src; size_t in_bs = src_bstride;
-    int log_Rp = 0;
+    int log_Rp = log_r0;
     for (int k = 0; k < P; k++) {
       T* out; size_t out_bs;
       if (k == P - 1) { out = dst; out_bs = dst_bstride; }
@@ -230,15 +282,16 @@ template <class F> struct Ctx : CtxBase {
       pp.src = in; pp.dst = out; pp.src_bstride = in_bs; pp.dst_bstride = out_bs;
       pp.n_in = (k == 0) ? n_in : n;
       pp.tw_lo = pl->tw_lo.template as<T>(); pp.tw_hi = pl->tw_hi.template as<T>(); pp.w_r = pl->w_r[k].template as<T>();
+      pp.vtw = pl->vtw.template as<T>(); pp.w0 = pl->w0.template as<T>();
       pp.scale = (inverse && k == P - 1) ? pl->n_inv : F::from_u64(1);
       pp.log_n = log_n; pp.log_r = pl->K[k]; pp.log_Rp = log_Rp; pp.lo_bits = pl->lo_bits;
+      pp.log_r0 = (k == 0) ? log_r0 : 0; pp.log_rho = (k == 0) ? pl->log_rho : 0;
       const int cols_log = log_n - pl->K[k];
       pp.log_C = cols_log < msntt::TILE_LOG_C ? cols_log : msntt::TILE_LOG_C;
-      pp.first = (k == 0); pp.last = (k == P - 1);
+      pp.last = (k == P - 1);
       const size_t tiles = ((size_t)1 << cols_log) >> pp.log_C;
-      const size_t lds = msntt::PassKernel<F>::lds_bytes(pp.log_r, pp.log_C);
-      next_bytes = (double)(n_in + n) * batch * sizeof(T) / P;  // (n_in + n)*s per transform, shared by its P passes
-      CK(run<msntt::PassKernel<F>>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, msntt::THREADS, lds, pp));
+      next_bytes = (double)(n_in + n) * batch * sizeof(T) / P;  // (n_in + n)*s per transform, shared by its P real passes
+      if (inverse) CK(launch_pass<true>(pp, tiles, batch)); else CK(launch_pass<false>(pp, tiles, batch));
       in = out; in_bs = out_bs;
       log_Rp += pl->K[k];
     }
@@ -324,6 +377,10 @@ template <class F> struct Ctx : CtxBase {
 
   int init(int dev, u32 flags) {
     device = dev; zae = (flags & MS_FLAG_ZERO_DISPLAY_EMPTY) ? 1 : 0;
+    if (const char* e = getenv("MS_NTT_KMAX")) { int v = atoi(e); if (v >= 5 && v <= msntt::MAX_LOG_R) ntt_kmax = v; }
+    if (const char* e = getenv("MS_NTT_MAXPAD")) { int v = atoi(e); if (v >= 0 && v <= msntt::MAX_LOG_PAD) ntt_maxpad = v; }
+    if (const char* e = getenv("MS_NTT_MAXRHO")) { int v = atoi(e); if (v >= 0 && v <= msntt::MAX_LOG_RHO) ntt_maxrho = v; }
+    if (const char* e = getenv("MS_NTT_TH512")) ntt_th512 = atoi(e);
     CK(msrt::set_device(dev));
     CK(msrt::stream_create(&own_stream));
     stream = own_stream;
@@ -333,7 +390,7 @@ template <class F> struct Ctx : CtxBase {
     return 0;
   }
   ~Ctx() {
-    for (auto& kv : plans) { kv.second->tw_lo.release(); kv.second->tw_hi.release(); for (auto& b : kv.second->w_r) b.release(); delete kv.second; }
+    for (auto& kv : plans) { kv.second->tw_lo.release(); kv.second->tw_hi.release(); kv.second->vtw.release(); kv.second->w0.release(); for (auto& b : kv.second->w_r) b.release(); delete kv.second; }
     for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
     DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg};
     for (DevBuf* b : bufs) b->release();

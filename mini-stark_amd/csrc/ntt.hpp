@@ -6,22 +6,32 @@
 // and src/fri.rs:350 (FRI codeword; extension limbs are independent base
 // transforms because the domain points are base-field elements).
 //
-// Decomposition (self-sorting, no bit-reversal pass).  n = r_1 r_2 ... r_P.
+// Decomposition (self-sorting, no bit-reversal pass).  n = r_0 r_1 r_2 ... r_P.
 // After pass p the array holds A_p[k_rest * R_p + i_done]: `i_done` = the low
-// output digits already produced (R_p = r_1..r_p values), `k_rest` = the input
+// output digits already produced (R_p = r_0..r_p values), `k_rest` = the input
 // index digits not yet transformed.  Pass p+1 transforms the TOP digit of
 // k_rest (stride n / r) with an r-point DFT, multiplies by the inter-pass
-// twiddle w_{n/R_p}^(i_new * k_low) and stores to
-//        A_{p+1}[k_low * R_p * r + i_done + R_p * i_new].
+// twiddle and stores to  A_{p+1}[k_low * R_p * r + i_done + R_p * i_new].
+// The twiddle of an element is  w_n^(k_low * (its output index so far)).
+//
+// Zero padding (blowup): when only n_in <= n / r_0 inputs are non-zero
+// (r_0 = 2, 4 or 8) the first pass is VIRTUAL — an r_0-point DFT of
+// (x, 0, .., 0) is r_0 copies of x — and is folded into the load of the first
+// real pass:  A_1[k*r_0 + i_1] = x[k] * w_n^(i_1 k).  A blowup-8 LDE of 2^20
+// coefficients is then two real passes (2^10 x 2^10), not three.
+//
 // A workgroup owns a tile of r rows x C consecutive "columns" f = k_low*R_p +
-// i_done, so every global access is a run of C consecutive elements (C = 16:
-// 128 B for Goldilocks); the first pass writes its tile transposed (r
-// consecutive elements per column).  Algorithmic HBM traffic: 2 * n * sizeof(T)
-// per pass.
+// i_done, so global accesses are runs of C consecutive elements (C = 16: 128 B
+// for Goldilocks) or, when R_p < C, whole contiguous blocks of R_p * r elements
+// (transposed store).  Algorithmic HBM traffic: 2 * n * sizeof(T) per real pass.
 //
 // Inside a tile the r-point DFT runs as register sub-rounds of 2^b points
 // (b <= 4) with LDS exchanges between them: DIF, digits taken from the top,
 // results left digit-reversed in LDS and un-reversed by the store phase.
+// Goldilocks: every root of unity of order <= 64 is a power of two
+// (w_64 = 2^39 for the reference's generator), so the twiddles INSIDE a
+// sub-round are shifts + one reduction, not multiplications.
+// Tile rows are padded by one element (bank spreading).
 #pragma once
 #include "field.hpp"
 
@@ -29,7 +39,8 @@ namespace msntt {
 
 constexpr int TILE_LOG_C = 4;       // 16 columns per tile
 constexpr int MAX_LOG_R = 10;       // tile rows <= 1024
-constexpr int THREADS = 256;
+constexpr int MAX_LOG_PAD = 3;      // zero-padding factor folded into the virtual first pass <= 8
+constexpr int MAX_LOG_RHO = 2;      // ... times a real radix <= 4 over the non-zero input blocks
 
 // sub-round digit sizes for a tile of 2^K rows (top digit first)
 MS_HD int subround_count(int K) { return K <= 4 ? 1 : (K <= 8 ? 2 : 3); }
@@ -45,34 +56,68 @@ template <class F> struct PassParams {
   typedef typename F::T T;
   const T* src; T* dst;
   size_t src_bstride, dst_bstride;  // elements between consecutive batch entries (blockIdx.y)
-  size_t n_in;                      // valid input elements (zero padded up to n); first pass only
+  size_t n_in;                      // valid input elements (zero padded); first real pass only
   const T* tw_lo; const T* tw_hi;   // w_n^j = tw_lo[j & lo_mask] * tw_hi[j >> lo_bits]
   const T* w_r;                     // w_r^j, j < r
+  const T* vtw;                     // virtual pass: w_(r0*r)^j, j < r0*r
+  const T* w0;                      // virtual pass: w_(r0)^j, j < r0
   T scale;                          // multiplied into the output of the last pass (1 = none)
   u32 log_n, log_r, log_Rp, log_C, lo_bits;
-  u32 first, last;
+  u32 log_r0 /* >0: this pass loads through a virtual r0-point pass */, log_rho /* of whose inputs 2^log_rho blocks are non-zero */;
+  u32 last;
 };
 
-template <class F, int B> MS_DEV void dif_regs(typename F::T (&x)[1 << B], const typename F::T* w_r, int log_r) {
-  // in-register DIF of 2^B points; output left in bit-reversed register order.
-  // stage twiddles w_{2h}^j = w_r[j * r / (2h)]
-#pragma unroll
-  for (int s = B - 1; s >= 0; s--) {
-    const int h = 1 << s;
-#pragma unroll
-    for (int blk = 0; blk < (1 << B); blk += 2 * h) {
-#pragma unroll
-      for (int j = 0; j < h; j++) {
-        typename F::T a = x[blk + j], b = x[blk + j + h];
-        x[blk + j] = F::add(a, b);
-        typename F::T d = F::sub(a, b);
-        if (j != 0) d = F::mul(d, w_r[(size_t)j << (log_r - s - 1)]);
-        x[blk + j + h] = d;
-      }
-    }
+// ---- Goldilocks shift twiddles ------------------------------------------------
+// x * 2^S mod p for a compile-time S in [0, 96)
+template <int S> MS_HD u64 gl_mul_pow2(u64 x) {
+  static_assert(S >= 0 && S < 96, "shift out of range");
+  if constexpr (S == 0) return x;
+  else if constexpr (S < 64) return GL::reduce128(x << S, x >> (64 - S));
+  else {  // x*2^S = x*2^(S-32)*2^32 = x*2^(S-32)*(2^64 - ... ) : use 2^64 == 2^32 - 1:  x*2^S == x*2^(S-32) - x*2^(S-64)
+    constexpr int A = S - 32, B = S - 64;  // 32 <= A < 64, 0 <= B < 32
+    const u64 alo = x << A, ahi = x >> (64 - A);
+    const u64 blo = x << B, bhi = (B == 0) ? 0 : (x >> ((64 - B) & 63));
+    const u64 lo = alo - blo;
+    const u64 hi = ahi - bhi - (alo < blo ? 1 : 0);
+    return GL::reduce128(lo, hi);
   }
 }
-MS_HD int bitrev(int v, int bits) { int r = 0; for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i); return r; }
+// (a - b) * w_(2^LOG2H2)^J for the reference's roots: w_64 = 2^39 (forward), 2^153 (inverse)
+template <class F, bool INV, int LOG2H2, int J> struct TwMul;
+template <bool INV, int LOG2H2, int J> struct TwMul<GL, INV, LOG2H2, J> {
+  static constexpr int EXP = ((INV ? 153 : 39) * (64 >> LOG2H2) * J) % 192;
+  static MS_HD u64 diff_mul(u64 a, u64 b, const u64* w_r, int log_r) {
+#ifdef MS_NTT_NO_SHIFT
+    return GL::mul(GL::sub(a, b), w_r[(size_t)J << (log_r - LOG2H2)]);
+#else
+    (void)w_r; (void)log_r;
+    if constexpr (EXP >= 96) return gl_mul_pow2<EXP - 96>(GL::sub(b, a));  // 2^96 == -1
+    else return gl_mul_pow2<EXP>(GL::sub(a, b));
+#endif
+  }
+};
+template <bool INV, int LOG2H2, int J> struct TwMul<BB, INV, LOG2H2, J> {
+  static MS_HD u32 diff_mul(u32 a, u32 b, const u32* w_r, int log_r) { return BB::mul(BB::sub(a, b), w_r[(size_t)J << (log_r - LOG2H2)]); }
+};
+
+template <class F, bool INV, int B, int S, int BLK, int J> struct DifStage {
+  // butterflies of stage S (distance 2^S) inside a 2^B-point DIF, unrolled at compile time
+  static MS_DEV void run(typename F::T (&x)[1 << B], const typename F::T* w_r, int log_r) {
+    constexpr int h = 1 << S;
+    typename F::T a = x[BLK + J], b = x[BLK + J + h];
+    x[BLK + J] = F::add(a, b);
+    if constexpr (J == 0) x[BLK + J + h] = F::sub(a, b);
+    else x[BLK + J + h] = TwMul<F, INV, S + 1, J>::diff_mul(a, b, w_r, log_r);
+    if constexpr (J + 1 < h) DifStage<F, INV, B, S, BLK, J + 1>::run(x, w_r, log_r);
+    else if constexpr (BLK + 2 * h < (1 << B)) DifStage<F, INV, B, S, BLK + 2 * h, 0>::run(x, w_r, log_r);
+    else if constexpr (S > 0) DifStage<F, INV, B, S - 1, 0, 0>::run(x, w_r, log_r);
+  }
+};
+// in-register DIF of 2^B points; output left in bit-reversed register order
+template <class F, bool INV, int B> MS_DEV void dif_regs(typename F::T (&x)[1 << B], const typename F::T* w_r, int log_r) {
+  DifStage<F, INV, B, B - 1, 0, 0>::run(x, w_r, log_r);
+}
+MS_HD constexpr int bitrev(int v, int bits) { int r = 0; for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i); return r; }
 
 // LDS row -> output digit index (and back) for the digit-reversed tile
 MS_HD int row_to_inew(int row, int K) {
@@ -96,57 +141,139 @@ MS_HD int inew_to_row(int inew, int K) {
   return row;
 }
 
-template <class F> struct PassKernel {
+template <class F, bool INV, int TH> struct PassKernel {
   typedef typename F::T T;
   typedef PassParams<F> Params;
-  static constexpr int THREADS = msntt::THREADS;
+  static constexpr int THREADS = TH;
+#ifdef MS_NTT_MINWAVES
+  static constexpr int MIN_WAVES = MS_NTT_MINWAVES;
+#endif
 
   static MS_HD int nphases(const Params& p) { return 2 + subround_count((int)p.log_r); }
-  static MS_HD size_t lds_bytes(int log_r, int log_C) {
-    size_t C = (size_t)1 << log_C, CP = C + (C > 1 ? 1 : 0);
-    return (((size_t)1 << log_r) * CP + ((size_t)1 << log_r)) * sizeof(T);
+  // LDS: tile r*C | w_r table r | store-twiddle table nk*r | small tables
+  static MS_HD int n_klow(int log_Rp, int log_C) { return log_Rp >= log_C ? 1 : (1 << (log_C - log_Rp)); }
+  // the store twiddles of a tile come from LDS tables when the tile spans at most two k_low values
+#ifndef MS_NTT_TAB  // measured neutral on MI355X (r01): off by default, saves LDS
+  static MS_HD bool use_tab(int, int, bool) { return false; }
+#else
+  static MS_HD bool use_tab(int log_Rp, int log_C, bool last) { return !last && n_klow(log_Rp, log_C) <= 2; }
+#endif
+  static MS_HD size_t lds_bytes(int log_r, int log_C, int log_Rp, bool last) {
+    const size_t r = (size_t)1 << log_r, C = (size_t)1 << log_C;
+#ifndef MS_NTT_SWZ
+    size_t el = r * (C + (C > 1 ? 1 : 0)) + r;
+#else
+    size_t el = r * C + r;
+#endif
+    if (use_tab(log_Rp, log_C, last)) el += (size_t)n_klow(log_Rp, log_C) * (r + 64 + 32);
+    return el * sizeof(T);
+  }
+  // swizzled tile index: unpadded rows of C elements; for C == 16 (128-B rows of u64) the 128-B half a row
+  // occupies inside its 256-B pair is flipped by the parity of row bits 1..4
+  static MS_HD int tix(int row, int cidx, int log_C) {
+#ifndef MS_NTT_SWZ  // rows padded by one element (the XOR-swizzled unpadded layout costs 75 more VGPRs: measured 1.6x slower)
+    return row * ((1 << log_C) + (log_C ? 1 : 0)) + cidx;
+#endif
+    if (log_C != TILE_LOG_C) return (row << log_C) + cidx;
+    const int half = (row ^ (row >> 1) ^ (row >> 2) ^ (row >> 3) ^ (row >> 4)) & 1;
+    return ((row >> 1) << (TILE_LOG_C + 1)) | (half << TILE_LOG_C) | cidx;
   }
 
   template <int B>
-  static MS_DEV void subround(const Params& p, int tid, int nthreads, T* tile, const T* w, int s_lo) {
-    const int K = (int)p.log_r, C = 1 << p.log_C, CP = C + (C > 1 ? 1 : 0);
+  static MS_DEV void subround(const Params& p, int tid, T* tile, const T* w, int s_lo) {
+    const int K = (int)p.log_r, C = 1 << p.log_C, lc = (int)p.log_C;
     const int q = 1 << s_lo;                      // row distance between the 2^B points
     const int items = (1 << (K - B)) << p.log_C;  // work items in the tile
-    for (int it = tid; it < items; it += nthreads) {
+    for (int it = tid; it < items; it += TH) {
       const int cidx = it & (C - 1);
       const int g = it >> p.log_C;           // (hi, lo) packed
       const int lo = g & (q - 1), hi = g >> s_lo;
       const int row0 = (hi << (s_lo + B)) + lo;
       T x[1 << B];
 #pragma unroll
-      for (int t = 0; t < (1 << B); t++) x[t] = tile[(row0 + t * q) * CP + cidx];
-      dif_regs<F, B>(x, w, K);
+      for (int t = 0; t < (1 << B); t++) x[t] = tile[tix(row0 + t * q, cidx, lc)];
+      dif_regs<F, INV, B>(x, w, K);
       // x[bitrev(e)] = y[e]; twiddle w_{q 2^B}^(e*lo) = w_r[e * lo * r / (q 2^B)]
 #pragma unroll
       for (int e = 0; e < (1 << B); e++) {
         T v = x[bitrev(e, B)];
         if (e != 0 && lo != 0) v = F::mul(v, w[((size_t)(e * lo)) << (K - s_lo - B)]);
-        tile[(row0 + e * q) * CP + cidx] = v;
+        tile[tix(row0 + e * q, cidx, lc)] = v;
       }
     }
   }
 
-  static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int nthreads, unsigned char* lds) {
-    const int K = (int)p.log_r, r = 1 << K, C = 1 << p.log_C, CP = C + (C > 1 ? 1 : 0);
+  static MS_DEV T tw_global(const Params& p, size_t e) {
+    T tw = p.tw_lo[e & (((size_t)1 << p.lo_bits) - 1)];
+    const size_t eh = e >> p.lo_bits;
+    if (eh) tw = F::mul(tw, p.tw_hi[eh]);
+    return tw;
+  }
+
+  static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int, unsigned char* lds) {
+    const int K = (int)p.log_r, r = 1 << K, C = 1 << p.log_C, lc = (int)p.log_C;
     T* tile = reinterpret_cast<T*>(lds);
-    T* w = tile + (size_t)r * CP;
+#ifndef MS_NTT_SWZ
+    T* w = tile + (size_t)r * (C + (C > 1 ? 1 : 0));
+#else
+    T* w = tile + (size_t)r * C;
+#endif
+    T* tabA = w + r;                                  // [nk][r]   t_k^(Rp * i_new)
+    const int nk = n_klow((int)p.log_Rp, lc);
+    T* tlow = tabA + (size_t)nk * r;                  // [nk][32]  g^j
+    T* thigh = tlow + (size_t)nk * 32;                // [nk][32]  g^(32 j)
+    T* tabB = thigh + (size_t)nk * 32;                // [nk][32]  t_k^(i_done)   (virtual pass only)
     const size_t n = (size_t)1 << p.log_n;
     const size_t col_stride = n >> K;  // n / r : distance between tile rows in the source
     const size_t f0 = (size_t)bx << p.log_C;
     const int S = subround_count(K);
+    const bool transposed = (int)p.log_Rp < lc;       // output of each k_low is one contiguous block
+    const bool tab = use_tab((int)p.log_Rp, lc, p.last != 0);
     if (ph == 0) {
       const T* src = p.src + (size_t)by * p.src_bstride;
-      for (int idx = tid; idx < r * C; idx += nthreads) {
-        const int row = idx >> p.log_C, cidx = idx & (C - 1);
-        const size_t a = f0 + cidx + (size_t)row * col_stride;
-        tile[row * CP + cidx] = (a < p.n_in) ? src[a] : (T)0;
+      if (p.log_r0 == 0) {
+        for (int idx = tid; idx < r * C; idx += TH) {
+          const int row = idx >> p.log_C, cidx = idx & (C - 1);
+          const size_t a = f0 + cidx + (size_t)row * col_stride;
+          tile[tix(row, cidx, lc)] = (a < p.n_in) ? src[a] : (T)0;
+        }
+      } else {
+        // virtual r0-point first pass over x[k2 + (n/r0) k1], of which only blocks k1 < rho are non-zero:
+        //   A_1[k2*r0 + i1] = w_n^(i1 k2) * sum_{k1 < rho} w_r0^(i1 k1) x[k2 + (n/r0) k1].
+        // The k_low part of w_n^(i1 k2) is merged into the store twiddle, the k_top part is w_(r0 r)^(i1 k_top).
+        const int r0m = (1 << p.log_r0) - 1, rho = 1 << p.log_rho;
+        const size_t nprime = n >> (p.log_r0 + K), blk = n >> p.log_r0;
+        for (int idx = tid; idx < r * C; idx += TH) {
+          const int row = idx >> p.log_C, cidx = idx & (C - 1);
+          const size_t f = f0 + cidx;
+          const int i1 = (int)(f & r0m);
+          const size_t k = (f >> p.log_r0) + nprime * (size_t)row;
+          T v = (k < p.n_in) ? src[k] : (T)0;
+          for (int k1 = 1; k1 < rho; k1++) {
+            const size_t kk = k + blk * (size_t)k1;
+            T x = (kk < p.n_in) ? src[kk] : (T)0;
+            const int e = (i1 * k1) & r0m;
+            if (e) x = F::mul(x, p.w0[e]);
+            v = F::add(v, x);
+          }
+          if (i1) v = F::mul(v, p.vtw[(size_t)i1 * row]);
+          tile[tix(row, cidx, lc)] = v;
+        }
       }
-      for (int j = tid; j < r; j += nthreads) w[j] = p.w_r[j];
+      for (int j = tid; j < r; j += TH) w[j] = p.w_r[j];
+      if (tab && tid < nk * 64) {
+        // per k_low: t = w_n^(k_low), g = t^Rp; tlow[j] = g^j, thigh[j] = g^(32 j)  (j < 32)
+        const int kk = tid >> 6, j = tid & 63;
+        const size_t k_low = (f0 >> p.log_Rp) + kk;
+        const T g = tw_global(p, (k_low << p.log_Rp));
+        T base = g;
+        if (j >= 32) { for (int s = 0; s < 5; s++) base = F::mul(base, base); }  // g^32
+        T acc = F::from_u64(1);
+        const int e = j & 31;
+        for (int b = 0; b < 5; b++) { if ((e >> b) & 1) acc = F::mul(acc, base); base = F::mul(base, base); }
+        (j < 32 ? tlow : thigh)[kk * 32 + e] = acc;
+        if (p.log_r0 && j < (1 << p.log_r0)) tabB[kk * 32 + j] = tw_global(p, k_low * (size_t)j);
+      }
       return;
     }
     if (ph <= S) {
@@ -155,42 +282,54 @@ template <class F> struct PassKernel {
       for (int t = 0; t < s; t++) done += subround_bits(K, t);
       const int b = subround_bits(K, s);
       const int s_lo = K - done - b;
+      if (s == 0 && tab) {  // finish the store-twiddle table while the first exchange runs
+        for (int idx = tid; idx < nk * r; idx += TH) {
+          const int kk = idx >> K, i = idx & (r - 1);
+          tabA[idx] = F::mul(tlow[kk * 32 + (i & 31)], thigh[kk * 32 + (i >> 5)]);
+        }
+      }
       switch (b) {
-        case 1: subround<1>(p, tid, nthreads, tile, w, s_lo); break;
-        case 2: subround<2>(p, tid, nthreads, tile, w, s_lo); break;
-        case 3: subround<3>(p, tid, nthreads, tile, w, s_lo); break;
-        default: subround<4>(p, tid, nthreads, tile, w, s_lo); break;
+        case 1: subround<1>(p, tid, tile, w, s_lo); break;
+        case 2: subround<2>(p, tid, tile, w, s_lo); break;
+        case 3: subround<3>(p, tid, tile, w, s_lo); break;
+        default: subround<4>(p, tid, tile, w, s_lo); break;
       }
       return;
     }
     // store phase
     T* dst = p.dst + (size_t)by * p.dst_bstride;
-    const size_t lo_mask = ((size_t)1 << p.lo_bits) - 1;
     const bool do_scale = p.scale != F::from_u64(1);
-    for (int idx = tid; idx < r * C; idx += nthreads) {
-      int row, cidx, inew;
-      if (p.first) { cidx = idx >> K; inew = idx & (r - 1); row = inew_to_row(inew, K); }  // transposed: i_new fastest
-      else { row = idx >> p.log_C; cidx = idx & (C - 1); inew = row_to_inew(row, K); }
-      T v = tile[row * CP + cidx];
-      const size_t f = f0 + cidx;
-      const size_t k_low = f >> p.log_Rp, i_done = f & (((size_t)1 << p.log_Rp) - 1);
-      if (!p.last) {
-        const size_t e = ((size_t)inew * k_low) << p.log_Rp;  // exponent of w_n, < n
-        if (e != 0) {
-          T tw = p.tw_lo[e & lo_mask];
-          const size_t eh = e >> p.lo_bits;
-          if (eh) tw = F::mul(tw, p.tw_hi[eh]);
-          v = F::mul(v, tw);
+    const int Rp_m = (1 << p.log_Rp) - 1;
+    for (int idx = tid; idx < r * C; idx += TH) {
+      int row, cidx, inew, kk, i_done;
+      if (transposed) {  // (i_done, i_new) fastest: each k_low writes Rp*r contiguous elements
+        kk = idx >> (K + p.log_Rp);
+        const int j = idx & ((r << p.log_Rp) - 1);
+        i_done = j & Rp_m; inew = j >> p.log_Rp;
+        cidx = (kk << p.log_Rp) + i_done; row = inew_to_row(inew, K);
+      } else {
+        row = idx >> p.log_C; cidx = idx & (C - 1); inew = row_to_inew(row, K);
+        kk = 0; i_done = (int)((f0 + cidx) & Rp_m);
+      }
+      T v = tile[tix(row, cidx, lc)];
+      const size_t k_low = (f0 + cidx) >> p.log_Rp;
+      if (!p.last && k_low) {
+        if (tab) {
+          v = F::mul(v, tabA[(kk << K) + inew]);
+          if (p.log_r0 && i_done) v = F::mul(v, tabB[kk * 32 + i_done]);
+        } else {  // w_n^(k_low * (output index so far)); the i_done term belongs to the virtual pass
+          const size_t e = k_low * (((size_t)inew << p.log_Rp) + (p.log_r0 ? (size_t)i_done : 0));
+          if (e) v = F::mul(v, tw_global(p, e));
         }
       }
       if (do_scale) v = F::mul(v, p.scale);
-      const size_t out = ((k_low << p.log_Rp) << K) + i_done + ((size_t)inew << p.log_Rp);
+      const size_t out = ((k_low << p.log_Rp) << K) + ((size_t)(f0 + cidx) & (size_t)Rp_m) + ((size_t)inew << p.log_Rp);
       dst[out] = v;
     }
   }
 };
 
-// out[k] = in[k] * s^k * mult  (k < n) — the coset pre-scaling of
+// out[k] = in[k] * s^k  (k < n) — the coset pre-scaling of
 // Radix2EvaluationDomain::get_coset(shift).fft (starks.rs:82-89).
 template <class F> struct ScalePowKernel {
   typedef typename F::T T;
@@ -198,7 +337,7 @@ template <class F> struct ScalePowKernel {
   static constexpr int ITEMS = 16;
   struct Params { const T* src; T* dst; size_t src_bstride, dst_bstride, n; T s, s_step /* s^THREADS */; };
   static MS_HD int nphases(const Params&) { return 1; }
-  static MS_DEV void phase(int, const Params& p, int bx, int by, int tid, int nthreads, unsigned char*) {
+  static MS_DEV void phase(int, const Params& p, int bx, int by, int tid, int, unsigned char*) {
     size_t k = (size_t)bx * (THREADS * ITEMS) + tid;
     if (k >= p.n) return;
     const T* src = p.src + (size_t)by * p.src_bstride;

@@ -78,8 +78,11 @@ inline int event_destroy(Event* e) { return (int)hipEventDestroy(e); }
 inline int event_record(Event* e, Stream* s) { return (int)hipEventRecord(e, s); }
 inline int event_elapsed_ms(float* ms, Event* a, Event* b) { return (int)hipEventElapsedTime(ms, a, b); }
 
+// optional K::MIN_WAVES = minimum waves per SIMD the register allocator must leave room for
+template <class K, class = void> struct MinWaves { static constexpr int v = 1; };
+template <class K> struct MinWaves<K, decltype((void)K::MIN_WAVES)> { static constexpr int v = K::MIN_WAVES; };
 template <class K>
-__global__ void __launch_bounds__(K::THREADS) ms_kmain(const typename K::Params p) {
+__global__ void __launch_bounds__(K::THREADS, MinWaves<K>::v) ms_kmain(const typename K::Params p) {
   extern __shared__ __align__(16) unsigned char ms_lds[];
   const int nph = K::nphases(p);
   for (int ph = 0; ph < nph; ph++) {
@@ -90,6 +93,14 @@ __global__ void __launch_bounds__(K::THREADS) ms_kmain(const typename K::Params 
 template <class K>
 inline int launch(Stream* s, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
   if (threads != K::THREADS) return (int)hipErrorInvalidValue;
+  if (lds_bytes > 65536) {  // opt in to more than 64 KiB of dynamic LDS (once per kernel)
+    static size_t granted = 0;
+    if (lds_bytes > granted) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ms_kmain<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return (int)e;
+      granted = lds_bytes;
+    }
+  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(ms_kmain<K>), dim3(gx, gy, 1), dim3(threads, 1, 1), lds_bytes, s, p);
   return (int)hipGetLastError();
 }

@@ -66,3 +66,23 @@ def test_prove_multilevel_scan(mk):
 @pytest.mark.parametrize("field", [0, 1])
 def test_error_codes(mk, field):
     pc.case_errors(mk, field)
+
+
+@pytest.mark.parametrize("kmax", ["5", "6", "7"])
+def test_ntt_virtual_pass_variants(kmax, monkeypatch):
+    """Small tiles force the multi-pass plans (virtual radix 8x{1,2,4} first pass, 2-4 real passes)
+    that full-size transforms use on the GPU."""
+    monkeypatch.setenv("MS_NTT_KMAX", kmax)
+    ctxs = {}
+
+    def mk2(field, fresh=False):
+        if field not in ctxs:
+            ctxs[field] = ms.Context(field, lib_path=EMU)
+        return ctxs[field]
+    for field in (0, 1):
+        for log_n, blowup in [(9, 2), (9, 4), (10, 8), (12, 8), (13, 8), (11, 16)]:
+            pc.case_coset_lde(mk2, field, log_n, blowup)
+        pc.case_ntt(mk2, field, 13)
+        pc.case_ntt(mk2, field, 16, batch=1)
+    pc.case_prove(mk2, 0, 10, 8, read_big=False)
+    pc.case_prove(mk2, 1, 9, 8, read_big=False)
