@@ -48,18 +48,9 @@ def main():
     import mini_stark_amd as ms
     from mini_stark_amd.stark import Stark, StarkConfig, fibonacci_air
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    from mini_stark_amd.dist import Group
+    grp = Group("nccl")
+    world, rank, local_rank, dev = grp.world, grp.rank, grp.local_rank, grp.device
 
     N = 1 << args.log_rows
     steps = N - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
@@ -76,28 +67,18 @@ def main():
         with torch.cuda.stream(stream):
             return stark.prove(tt, trace_device_ptr=d_trace.data_ptr(), read_fri_proof=False)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     proof = None
     for _ in range(args.warmup):
         proof = step()
-    barrier()
+    grp.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         proof = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        # every rank's final FRI root, gathered over RCCL (outside the timed region): proves all ranks finished
-        mine = torch.frombuffer(bytearray(proof.fri_roots[-1]), dtype=torch.uint8).to(dev)
-        allr = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
+    grp.barrier()
+    elapsed = grp.max_over_ranks(time.perf_counter() - t0)
+    # every rank's final FRI root, gathered over RCCL (outside the timed region): all ranks finished a proof
+    final_roots = grp.all_gather_bytes(proof.fri_roots[-1])
+    assert len(final_roots) == world
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
 
@@ -152,9 +133,7 @@ def main():
                                    "sample": f"one 2^{cl}-row proof of the same AIR on the oracle (oracle/ministark_oracle.cpp, 1 thread) took {ct:.2f} s; "
                                              f"scaled linearly x{int(scale)} to 2^{args.log_rows} rows (optimistic for the CPU: ignores the log factor)"}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,35 @@
+"""The C-ABI library loads (no GPU needed to dlopen) and exports every symbol include/ministark.h declares."""
+import ctypes
+import os
+import re
+
+import mini_stark_amd as ms
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ministark.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ms_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    path = ms.library_path()
+    assert os.path.exists(path), "libministark.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(path)
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_emulation_build_exports_same_abi():
+    emu = ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libministark_emu.so"))
+    assert not [s for s in declared_symbols() if not hasattr(emu, s)]
+
+
+def test_no_fallback_when_library_missing(tmp_path):
+    import pytest
+    with pytest.raises(ms.MsError):
+        ms.Context(ms.GOLDILOCKS, lib_path=str(tmp_path / "nope.so"))
