@@ -45,7 +45,7 @@ def build_library(force=False):
 
 
 def load_library(path=None):
-    path = path or library_path()
+    path = path or os.environ.get("MS_LIB") or library_path()  # MS_LIB: tuning builds of the same HIP library (tools/*_exp.sh)
     if path in _LIBS:
         return _LIBS[path]
     if not os.path.exists(path):

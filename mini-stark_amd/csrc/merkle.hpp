@@ -22,6 +22,7 @@
 namespace msmerkle {
 
 constexpr int THREADS = 256;
+struct alignas(16) uint4_t { u32 x, y, z, w; };
 
 MS_HD u32 rotr32(u32 x, int n) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -31,6 +32,14 @@ MS_HD u32 rotr32(u32 x, int n) {
 #endif
 }
 MS_HD u32 bswap32(u32 x) { return __builtin_bswap32(x); }
+// a ^ b ^ c in one instruction on gfx950 (v_bitop3_b32, truth table 0x96)
+MS_HD u32 xor3(u32 a, u32 b, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
 
 struct Sha256 {
   u32 st[8];
@@ -54,14 +63,14 @@ struct Sha256 {
     for (int i = 0; i < 64; i++) {
       if (i >= 16) {
         u32 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-        u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-        u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+        u32 s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+        u32 s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
         w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
       }
-      u32 S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+      u32 S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
       u32 ch = g ^ (e & (f ^ g));
       u32 t1 = h + S1 + ch + K[i] + w[i & 15];
-      u32 S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+      u32 S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
       u32 mj = (a & b) | (c & (a | b));
       u32 t2 = S0 + mj;
       h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
@@ -191,9 +200,11 @@ template <class F, int E> struct LeafHashKernel {
       }
       s.drain();  // the only compression site
     }
-    u32* out = p.nodes + g * 8;
-#pragma unroll
-    for (int k = 0; k < 8; k++) out[k] = bswap32(s.h.st[k]);
+    uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + g * 8);
+    uint4_t o0, o1;
+    o0.x = bswap32(s.h.st[0]); o0.y = bswap32(s.h.st[1]); o0.z = bswap32(s.h.st[2]); o0.w = bswap32(s.h.st[3]);
+    o1.x = bswap32(s.h.st[4]); o1.y = bswap32(s.h.st[5]); o1.z = bswap32(s.h.st[6]); o1.w = bswap32(s.h.st[7]);
+    out[0] = o0; out[1] = o1;
   }
 };
 
@@ -213,18 +224,27 @@ struct InnerHashKernel {
       Sha256 h; h.init();
       u32 w[16];
       for (u32 b = 0; b < p.ic / 2; b++) {
+        // two children = one 64-byte block, fetched as four 16-byte loads
+        const uint4_t* c4 = reinterpret_cast<const uint4_t*>(ch + b * 16);
 #pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = bswap32(ch[b * 16 + i]);
+        for (int q = 0; q < 4; q++) {
+          const uint4_t v = c4[q];
+          w[4 * q] = bswap32(v.x); w[4 * q + 1] = bswap32(v.y); w[4 * q + 2] = bswap32(v.z); w[4 * q + 3] = bswap32(v.w);
+        }
         h.compress(w);
       }
+      // padding block: 0x80, zeros, bit length.  With the constant length of the binary tree the whole
+      // message schedule of this block folds to literals at compile time.
       w[0] = 0x80000000u;
 #pragma unroll
       for (int i = 1; i < 15; i++) w[i] = 0;
-      w[15] = p.ic * 256u;  // message bits (ic * 32 bytes)
-      h.compress(w);
-      u32* out = p.nodes + (child_off + nchildren + g) * 8;
-#pragma unroll
-      for (int k = 0; k < 8; k++) out[k] = bswap32(h.st[k]);
+      if (p.ic == 2) { w[15] = 512u; h.compress(w); }
+      else { w[15] = p.ic * 256u; h.compress(w); }
+      uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + (child_off + nchildren + g) * 8);
+      uint4_t o0, o1;
+      o0.x = bswap32(h.st[0]); o0.y = bswap32(h.st[1]); o0.z = bswap32(h.st[2]); o0.w = bswap32(h.st[3]);
+      o1.x = bswap32(h.st[4]); o1.y = bswap32(h.st[5]); o1.z = bswap32(h.st[6]); o1.w = bswap32(h.st[7]);
+      out[0] = o0; out[1] = o1;
       if (stride == 0) break;
     }
   }
