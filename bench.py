@@ -47,7 +47,8 @@ def main():
     import numpy as np
     import torch
     import mini_stark_amd as ms
-    from mini_stark_amd.stark import Stark, StarkConfig, fibonacci_air
+    from mini_stark_amd.stark import StarkConfig, fibonacci_air
+    from mini_stark_amd.host import HostStark  # C++ mirror of StarkConfig::new / Stark::prove above the C ABI
 
     from mini_stark_amd.dist import Group
     grp = Group("nccl")
@@ -62,14 +63,15 @@ def main():
     ctx = ctxs[0]
     tts = [fibonacci_air(c, steps, secret_b=2 + rank * C_IN + i) for i, c in enumerate(ctxs)]
     cfg = StarkConfig(ctx, 20, args.blowup, steps, tts[0].constrain_number())
-    starks = [Stark(StarkConfig(c, 20, args.blowup, steps, tts[0].constrain_number())) for c in ctxs]
+    starks = [HostStark(c, 20, args.blowup, steps, tts[0].constrain_number()) for c in ctxs]
     d_traces = [torch.from_numpy(t.data.view(np.int64)).to(dev) for t in tts]  # resident in HBM before the timed region
     torch.cuda.synchronize()
     last = [None] * C_IN
 
     def prove_n(i, n):
         for _ in range(n):
-            last[i] = starks[i].prove(tts[i], trace_device_ptr=d_traces[i].data_ptr(), read_fri_proof=False)
+            ctxs[i].check(starks[i].prove_raw(tts[i], trace_device_ptr=d_traces[i].data_ptr(), read_fri_proof=False))
+        last[i] = starks[i].last_proof(read_fri_proof=False)
 
     def run_steps(n):  # n steps = n proofs on each of the C_IN in-flight lanes (ctypes releases the GIL inside the library)
         if C_IN == 1:

@@ -50,7 +50,7 @@ def load_library(path=None):
         return _LIBS[path]
     if not os.path.exists(path):
         raise MsError(ERR_HIP, f"{path} not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); there is no CPU fallback")
-    L = C.CDLL(path)
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)  # the C++ host mirror (libministark_host.so) resolves ms_* against it
     L.ms_last_error.restype = C.c_char_p
     L.ms_last_error.argtypes = [C.c_void_p]
     L.ms_fri_proof_size.restype = C.c_size_t

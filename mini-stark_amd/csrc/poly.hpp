@@ -348,15 +348,19 @@ template <class F, int E> struct SuffixHornerKernel {
 };
 
 // ---------------------------------------------------------------- Degree / FindFirst
-// result[by] = max(j+1) over nonzero elements (0 for the zero polynomial); caller zeroes result.
+// result = max(j+1) over nonzero elements (0 for the zero polynomial); caller zeroes result.
+// Elements are visited from the top: the first workgroups to run see the leading coefficient, publish the
+// answer, and every later workgroup leaves after one read of `result` (no loads, no atomics).
 template <class F, int E> struct DegreeKernel {
   typedef typename F::T T;
   static constexpr int THREADS = mspoly::THREADS;
   struct Params { const T* src; size_t limb_stride, n; unsigned long long* result; };
   static MS_HD int nphases(const Params&) { return 1; }
   static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
-    const size_t j = (size_t)bx * nthreads + tid;
-    if (j >= p.n) return;
+    const size_t r = (size_t)bx * nthreads + tid;
+    if (r >= p.n) return;
+    const size_t j = p.n - 1 - r;
+    if ((unsigned long long)(j + 1) <= *reinterpret_cast<volatile unsigned long long*>(p.result)) return;
     bool nz = false;
     for (int l = 0; l < E; l++) nz = nz || (p.src[(size_t)l * p.limb_stride + j] != 0);
     if (nz) msrt::atomic_max_u64(p.result, (unsigned long long)(j + 1));

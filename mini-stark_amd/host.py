@@ -1,0 +1,105 @@
+"""ctypes binding of the C++ host mirror (mini-stark_amd/host/stark_host.cpp: ministark::StarkConfig /
+Stark::prove / Transcript above the C ABI).  libministark_host.so contains no arithmetic: it calls the
+ms_* stage functions of whichever libministark build the Context was created from."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ._native import Context, MsError
+from .stark import FriProof, StarkProof
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_HOST = None
+
+
+def host_library_path():
+    return os.path.join(_HERE, "libministark_host.so")
+
+
+def build_host_library(force=False):
+    so, src = host_library_path(), os.path.join(_HERE, "host", "stark_host.cpp")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "ministark.h")
+    if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return so
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+    return so
+
+
+def _host():
+    global _HOST
+    if _HOST is None:
+        path = host_library_path()
+        if not os.path.exists(path):
+            raise MsError(-6, f"{path} not found: run __graft_entry__.build()")
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        L.msh_stark_new.restype = C.c_void_p
+        for n in ("msh_proof_arthur", "msh_proof_evals", "msh_proof_fri_roots", "msh_proof_fri_blob", "msh_proof_challenges", "msh_proof_num_polys"):
+            getattr(L, n).restype = C.c_size_t
+        _HOST = L
+    return _HOST
+
+
+class HostStark:
+    """StarkConfig::new + Stark::new + Stark::prove (src/starks.rs:268-310, 40-57, 59-169) in C++."""
+
+    def __init__(self, ctx: Context, security_bits: int, blowup_factor: int, steps: int, trace_columns: int):
+        self.H, self.ctx = _host(), ctx
+        err = C.c_int(0)
+        self.h = C.c_void_p(self.H.msh_stark_new(ctx.h, C.c_int(ctx.field), C.c_uint64(security_bits), C.c_uint64(blowup_factor), C.c_uint64(steps),
+                                                 C.c_uint64(trace_columns), C.byref(err)))
+        if not self.h.value:
+            raise MsError(err.value, "STARK Config: security bits has to be at least 20")
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.H.msh_stark_config(self.h, C.byref(a), C.byref(b), C.byref(c))
+        self.rounds, self.constrain_queries, self.fri_queries = a.value, b.value, c.value
+
+    def __del__(self):
+        try:
+            if self.h is not None and self.h.value:
+                self.H.msh_stark_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def prove_raw(self, trace, trace_device_ptr=None, read_fri_proof=True):
+        """Runs the proof; returns the status code only (the bench loop)."""
+        if not hasattr(trace, "_lin"):
+            k = np.array([len(i) for _, i in trace.transitions], dtype=np.int32)
+            sc = np.array([v for s, _ in trace.transitions for v in s], dtype=np.uint64)
+            ix = np.array([v for _, i in trace.transitions for v in i], dtype=np.int32)
+            trace._lin = (k, sc, ix)
+        k, sc, ix = trace._lin
+        host_ptr = None if trace_device_ptr is not None else trace.data.ctypes.data_as(C.POINTER(C.c_uint64))
+        return self.H.msh_stark_prove(self.h, host_ptr, C.c_void_p(trace_device_ptr), C.c_size_t(trace.length), C.c_size_t(trace.width), C.c_int(len(k)),
+                                      k.ctypes.data_as(C.POINTER(C.c_int)), sc.ctypes.data_as(C.POINTER(C.c_uint64)), ix.ctypes.data_as(C.POINTER(C.c_int)),
+                                      C.c_int(1 if read_fri_proof else 0))
+
+    def _bytes(self, fn):
+        n = fn(self.h, None, C.c_size_t(0))
+        buf = (C.c_uint8 * max(1, n))()
+        fn(self.h, buf, C.c_size_t(n))
+        return bytes(buf[:n])
+
+    def last_proof(self, read_fri_proof=True) -> StarkProof:
+        e = self.ctx.e
+        tc, lc = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
+        self.H.msh_proof_commits(self.h, tc, lc)
+        c = int(self.H.msh_proof_num_polys(self.h))
+        n = self.H.msh_proof_evals(self.h, None, C.c_size_t(0))
+        ev = np.zeros(max(1, n), dtype=np.uint64)
+        self.H.msh_proof_evals(self.h, ev.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(n))
+        ev = ev[:n].reshape(-1, c + 1, e)
+        roots = self._bytes(self.H.msh_proof_fri_roots)
+        n = self.H.msh_proof_challenges(self.h, None, C.c_size_t(0))
+        ch = np.zeros(max(1, n), dtype=np.uint64)
+        self.H.msh_proof_challenges(self.h, ch.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(n))
+        self.last_challenges = ch[:n]
+        blob = self._bytes(self.H.msh_proof_fri_blob) if read_fri_proof else b""
+        return StarkProof(self._bytes(self.H.msh_proof_arthur), bytes(tc), bytes(lc), ev[:, :c, :], ev[:, c, :],
+                          FriProof(blob, device_resident=not read_fri_proof), [roots[i:i + 32] for i in range(0, len(roots), 32)])
+
+    def prove(self, trace, trace_device_ptr=None, read_fri_proof=True) -> StarkProof:
+        self.ctx.check(self.prove_raw(trace, trace_device_ptr, read_fri_proof))
+        return self.last_proof(read_fri_proof)

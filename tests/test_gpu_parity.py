@@ -123,3 +123,12 @@ def test_full_size_properties(mk, field):
             bad = bytearray(proof); bad[8 * e + 3] ^= 0x40
             assert orc.fri_verify(field, e, rounds, betas, zs, Bs, als, b"".join(roots), bytes(bad)) == 0
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("field,steps,blowup", [(0, 9, 2), (1, 7, 2), (0, 1023, 8)])
+def test_host_mirror_on_gpu(mk, field, steps, blowup):
+    """C++ Stark::prove mirror == Python mirror on the HIP build (transcript, stage order, proof bytes)."""
+    from mini_stark_amd.host import build_host_library
+    import test_host_mirror as thm
+    build_host_library()
+    thm.check_pair(mk(field), steps, blowup)

@@ -1,0 +1,66 @@
+"""C++ host mirror (mini-stark_amd/host/stark_host.cpp) vs the Python mirror (mini-stark_amd/stark.py): same
+transcript, same stage order, byte-identical proofs; and the reference's own e2e configuration
+(tests/e2e_goldilocks.rs:65-75,98-114: steps 9, blowup 2, 20 bits; e2e_babybear.rs: steps 7) proves and its FRI
+part verifies under the oracle's verifier restatement."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mini_stark_amd as ms
+from mini_stark_amd.host import HostStark, build_host_library
+from mini_stark_amd.stark import Stark, StarkConfig, fibonacci_air
+from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu", "libministark_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+    build_host_library()
+    return EMU
+
+
+def check_pair(ctx, steps, blowup):
+    tt = fibonacci_air(ctx, steps)
+    cols = tt.constrain_number()
+    py = Stark(StarkConfig(ctx, 20, blowup, steps, cols)).prove(tt)
+    hs = HostStark(ctx, 20, blowup, steps, cols)
+    cc = hs.prove(tt)
+    assert (hs.rounds, hs.constrain_queries, hs.fri_queries) == (StarkConfig(ctx, 20, blowup, steps, cols).rounds,) + tuple(ctx.num_queries(20, blowup, steps)[1:])
+    assert cc.arthur == py.arthur and cc.trace_commit == py.trace_commit and cc.constrain_trace_commit == py.constrain_trace_commit
+    assert (cc.constrain_queries == py.constrain_queries).all() and (cc.validity_queries == py.validity_queries).all()
+    assert cc.fri_roots == py.fri_roots and cc.fri_proof.blob == py.fri_proof.blob
+    return hs, cc
+
+
+@pytest.mark.parametrize("field,steps,blowup", [(0, 9, 2), (1, 7, 2), (0, 63, 8), (1, 31, 4)])
+def test_host_mirror_matches_python_mirror(emu, field, steps, blowup):
+    ctx = ms.Context(field, lib_path=emu)
+    hs, proof = check_pair(ctx, steps, blowup)
+    # FRI part of the proof under the verifier restatement (fri.rs:191-245), challenges as recorded by the prover
+    e, ch = ctx.e, [int(v) for v in hs.last_challenges]
+    q = hs.constrain_queries
+    pos = 2 + q * e
+    zs, als = [], []
+    for _ in range(1, hs.rounds):
+        zs += ch[pos:pos + e]; als += ch[pos + e:pos + 2 * e]; pos += 2 * e
+    betas = ch[pos:]
+    assert len(betas) == hs.fri_queries
+    # B values are the prover messages in the transcript: arthur = trace_root | lde_root | per round (B (2e u64) | root)
+    ar = proof.arthur
+    Bs, off = [], 64
+    for _ in range(1, hs.rounds):
+        Bs += list(np.frombuffer(ar[off:off + 16 * e], dtype=np.uint64)); off += 16 * e + 32
+    assert orc.fri_verify(field, e, hs.rounds, betas, zs, [int(b) for b in Bs], als, b"".join(proof.fri_roots), proof.fri_proof.blob) == 1
+
+
+def test_low_security_bits_rejected(emu):
+    ctx = ms.Context(0, lib_path=emu)
+    with pytest.raises(ms.MsError):
+        HostStark(ctx, 19, 2, 9, 6)  # starks.rs:341-346 should_panic
+    with pytest.raises(ms.MsError):
+        StarkConfig(ctx, 1, 4, 128, 6)
