@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--field", type=int, default=0, help="0 Goldilocks, 1 BabyBear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-rows", type=int, default=18)
-    ap.add_argument("--inflight", type=int, default=3, help="independent proofs in flight per GPU (one ms_ctx + HIP stream each); a step = this many proofs")
+    ap.add_argument("--inflight", type=int, default=4, help="independent proofs in flight per GPU (one ms_ctx + HIP stream each); a step = this many proofs")
     args = ap.parse_args()
 
     import numpy as np

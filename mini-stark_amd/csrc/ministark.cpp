@@ -611,11 +611,14 @@ template <class F> struct Ctx : CtxBase {
   // ------------------------------------------------------------------ FRI rounds (fri.rs:314-352)
   Round* round_slot(size_t i) { while (rounds.size() <= i) rounds.push_back(new Round()); return rounds[i]; }
   // codeword + tree of rounds[i] from its coefficient limbs (ncoef_in valid coefficients)
-  int round_commit(Round* r, size_t ncoef_in) {
+  // `nonzero_limbs`: limbs >= this are identically zero (round 0: extend_poly embeds base coefficients), so their
+  // transform is all zeros and is not computed
+  int round_commit(Round* r, size_t ncoef_in, int nonzero_limbs = E) {
     if (ctz64(r->D) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "FRI domain larger than the field's two-adicity");
     RQ(tree_shape(r->D, 2, 2, &r->ts));  // starks.rs:290-295: leafs_per_node 2, inner_children 2
     if (r->cw.ensure(r->D * E * sizeof(T))) return fail(MS_ERR_NOMEM, "codeword");
-    RQ(ntt_run(ctz64(r->D), false, r->poly.template as<T>(), r->cap, ncoef_in, r->cw.template as<T>(), r->D, E));  // fri.rs:350
+    RQ(ntt_run(ctz64(r->D), false, r->poly.template as<T>(), r->cap, ncoef_in, r->cw.template as<T>(), r->D, (size_t)nonzero_limbs));  // fri.rs:350
+    if (nonzero_limbs < E) CK(msrt::memset_dev(r->cw.template as<T>() + (size_t)nonzero_limbs * r->D, 0, (size_t)(E - nonzero_limbs) * r->D * sizeof(T), stream));
     RQ((tree_build<E>(r->cw.template as<T>(), 0, 1, r->D, 1, r->ts, r->nodes)));                                       // fri.rs:351
     return 0;
   }
@@ -653,7 +656,7 @@ template <class F> struct Ctx : CtxBase {
     size_t dsize = (deg + 1) * blowup_;  // fri.rs:74 (quirk Q11)
     size_t D = 1; while (D < dsize) D <<= 1;
     r->D = D;
-    RQ(round_commit(r, nc));
+    RQ(round_commit(r, nc, 1));
     RQ(read_root(r->nodes, r->ts, root0));
     nrounds_done = 1;
     return MS_OK;
