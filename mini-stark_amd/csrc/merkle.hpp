@@ -89,15 +89,22 @@ template <int RW> struct ShaStream {
   static_assert((RW & (RW - 1)) == 0 && RW >= 32, "ring must be a power of two >= 2 blocks");
   Sha256 h;
   u32* ring; int nthreads, tid;
-  u32 cur;     // last bytes appended (big-endian)
+  u64 acc;     // the low 8*pend bits are bytes not yet emitted as a whole word
+  u32 pend;    // 0..3
   u32 total;   // bytes appended
   u32 done;    // bytes compressed
-  MS_HD void init(u32* lds_words, int nthreads_, int tid_) { h.init(); ring = lds_words; nthreads = nthreads_; tid = tid_; cur = 0; total = 0; done = 0; }
-  MS_HD void put(u32 ch) {
-    cur = (cur << 8) | ch;
-    total++;
-    if ((total & 3) == 0) ring[(((total >> 2) - 1) & (RW - 1)) * nthreads + tid] = cur;
+  MS_HD void init(u32* lds_words, int nthreads_, int tid_) { h.init(); ring = lds_words; nthreads = nthreads_; tid = tid_; acc = 0; pend = 0; total = 0; done = 0; }
+  // append the k (1..4) low-order bytes of w, most significant first
+  MS_HD void append(u32 w, u32 k) {
+    acc = (acc << (8 * k)) | (u64)(k == 4 ? w : (w & ((1u << (8 * k)) - 1u)));
+    pend += k;
+    if (pend >= 4) {
+      pend -= 4;
+      ring[((total >> 2) & (RW - 1)) * nthreads + tid] = (u32)(acc >> (8 * pend));
+    }
+    total += k;
   }
+  MS_HD void put(u32 ch) { append(ch, 1); }
   MS_HD void drain() {
     while (total - done >= 64) {
       u32 w[16];
@@ -111,52 +118,59 @@ template <int RW> struct ShaStream {
   // FIPS 180-4 padding; caller drains afterwards
   MS_HD void pad() {
     const u64 bits = (u64)total * 8;
-    put(0x80);
-    while ((total & 63) != 56) put(0);
-    for (int k = 7; k >= 0; k--) put((u32)(bits >> (8 * k)) & 0xff);
+    append(0x80, 1);
+    while (total & 3) append(0, 1);
+    while ((total & 63) != 56) append(0, 4);
+    append((u32)(bits >> 32), 4);
+    append((u32)bits, 4);
   }
 };
 
-// canonical decimal of a base element, most significant digit first, no
-// leading zeros; ZERO -> "" (zero_as_empty) or "0".
+// four decimal digits of c < 10^4 as big-endian ASCII
+MS_HD u32 pack4(u32 c) {
+  const u32 q = (c * 5243u) >> 19, r = c - q * 100u;      // c / 100, c % 100
+  const u32 d3 = (q * 205u) >> 11, d2 = q - d3 * 10u;      // q / 10, q % 10   (q < 100)
+  const u32 d1 = (r * 205u) >> 11, d0 = r - d1 * 10u;
+  return 0x30303030u + (d3 << 24) + (d2 << 16) + (d1 << 8) + d0;
+}
+// canonical decimal of a base element, most significant digit first, no leading zeros;
+// ZERO -> "" (zero_as_empty) or "0".  The value is split into 4-digit chunks that are appended as packed
+// words, skipping the leading zero characters of the zero-padded string.
 template <class F, class S> MS_HD void put_dec(S& s, typename F::T v_, int zero_as_empty) {
-  u64 v = F::to_u64(v_);
-  if (v == 0) { if (!zero_as_empty) s.put('0'); return; }
-  constexpr int ND = F::MAX_DIGITS;  // 20 (Goldilocks) / 10 (BabyBear)
-  u32 chunk[ND / 5];                 // 5-digit chunks, most significant first
-  if (ND == 20) {
-    u64 hi = v / 10000000000ULL, lo = v - hi * 10000000000ULL;  // hi < 1.85e9, lo < 1e10
-    u32 hi32 = (u32)hi;
-    u32 lo_hi = (u32)(lo / 100000ULL), lo_lo = (u32)(lo - (u64)lo_hi * 100000ULL);
-    chunk[0] = hi32 / 100000u; chunk[1] = hi32 - chunk[0] * 100000u;
-    chunk[ND / 5 - 2] = lo_hi; chunk[ND / 5 - 1] = lo_lo;
+  const u64 v = F::to_u64(v_);
+  if (v == 0) { if (!zero_as_empty) s.append('0', 1); return; }
+  constexpr int NCH = (F::MAX_DIGITS + 3) / 4;  // 5 (Goldilocks, 20 digits) / 3 (BabyBear, 10 digits -> 12 chars)
+  u32 c[NCH];
+  if (NCH == 5) {
+    const u64 hi = v / 100000000ULL; const u32 lo = (u32)(v - hi * 100000000ULL);       // hi < 1.85e11
+    const u32 hi2 = (u32)(hi / 100000000ULL); const u32 mid = (u32)(hi - (u64)hi2 * 100000000ULL);
+    c[0] = hi2; c[1] = mid / 10000u; c[2] = mid - c[1] * 10000u;
+    c[NCH - 2] = lo / 10000u; c[NCH - 1] = lo - c[NCH - 2] * 10000u;
   } else {
-    u32 x = (u32)v;
-    chunk[0] = x / 100000u; chunk[1] = x - chunk[0] * 100000u;
+    const u32 x = (u32)v;
+    c[0] = x / 100000000u; const u32 r = x - c[0] * 100000000u;
+    c[1] = r / 10000u; c[NCH - 1] = r - c[1] * 10000u;
   }
-  bool started = false;
+  u32 lead = 0; bool found = false;  // leading zero characters
 #pragma unroll
-  for (int c = 0; c < ND / 5; c++) {
-    u32 x = chunk[c];
-    u32 d4 = x / 10000u; x -= d4 * 10000u;
-    u32 d3 = x / 1000u; x -= d3 * 1000u;
-    u32 d2 = x / 100u; x -= d2 * 100u;
-    u32 d1 = x / 10u; u32 d0 = x - d1 * 10u;
-    started = started || d4; if (started) s.put('0' + d4);
-    started = started || d3; if (started) s.put('0' + d3);
-    started = started || d2; if (started) s.put('0' + d2);
-    started = started || d1; if (started) s.put('0' + d1);
-    started = started || d0; if (started) s.put('0' + d0);
+  for (int j = 0; j < NCH; j++) {
+    const u32 z = c[j] == 0 ? 4u : (c[j] < 10u ? 3u : (c[j] < 100u ? 2u : (c[j] < 1000u ? 1u : 0u)));
+    if (!found) lead += z;
+    found = found || (c[j] != 0);
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; j++) {
+    const int k = 4 * (j + 1) - (int)lead;
+    if (k > 0) s.append(pack4(c[j]), k > 4 ? 4u : (u32)k);
   }
 }
 template <class F, int E> struct Display {
   template <class S> static MS_HD void put(S& s, const typename F::T* c, int zae) {
-    const char* a = "QuadExtField(";
-    for (int i = 0; i < 13; i++) s.put((u32)a[i]);
+    s.append(0x51756164u, 4); s.append(0x45787446u, 4); s.append(0x69656c64u, 4); s.append('(', 1);  // "QuadExtField("
     Display<F, E / 2>::put(s, c, zae);
-    s.put(' '); s.put('+'); s.put(' ');
+    s.append(0x202b20u, 3);                                                                          // " + "
     Display<F, E / 2>::put(s, c + E / 2, zae);
-    s.put(' '); s.put('*'); s.put(' '); s.put('u'); s.put(')');
+    s.append(0x202a2075u, 4); s.append(')', 1);                                                      // " * u)"
   }
 };
 template <class F> struct Display<F, 1> {

@@ -49,7 +49,8 @@ def case_merkle(mk, field, leaf_num, ext, lpn, ic, special=False):
     leafs = rand_field(field, (leaf_num * ext,), seed=leaf_num + lpn)
     if special:  # zeros, small values, p-1, digit-count boundaries
         p = MODULUS[field]
-        vals = [0, 1, 9, 10, 99999, 100000, 10**9, 10**10 - 1, 10**10, p - 1, 10**19 % p, (10**19 - 1) % p, 2**32 % p, 12345678901234567890 % p]
+        vals = [0, 1, p - 1, 2**32 % p, 12345678901234567890 % p, 1000100010001 % p, 10203040506070809 % p]
+        vals += [v % p for k in range(1, 20) for v in (10**k - 1, 10**k, 10**k + 1, 7 * 10**k)]  # every digit-count boundary
         for i, v in enumerate(vals):
             leafs[i % leafs.size] = v % p
     rc, nodes, root = ctx.merkle_commit(leafs, ext, lpn, ic)
