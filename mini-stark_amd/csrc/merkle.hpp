@@ -224,20 +224,24 @@ template <class F, int E> struct LeafHashKernel {
 
 // Inner levels.  `nlevels` consecutive levels are processed by the launch: with
 // nlevels > 1 the grid must be a single workgroup (fused tree top).
-struct InnerHashKernel {
+// IC > 0: inner_children fixed at compile time (IC = 2 is the prover's tree, starks.rs:290-301: the padding block's
+// message schedule then folds to literals); IC = 0: taken from Params.
+struct InnerHashParams { u32* nodes; size_t child_off, nchildren; u32 ic; u32 nlevels; };
+template <int IC> struct InnerHashKernelT {
   static constexpr int THREADS = msmerkle::THREADS;
-  struct Params { u32* nodes; size_t child_off, nchildren; u32 ic; u32 nlevels; };
+  typedef InnerHashParams Params;
   static MS_HD int nphases(const Params& p) { return (int)p.nlevels; }
   static MS_DEV void phase(int ph, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
+    const u32 ic = IC ? (u32)IC : p.ic;
     size_t child_off = p.child_off, nchildren = p.nchildren;
-    for (int l = 0; l < ph; l++) { child_off += nchildren; nchildren /= p.ic; }
-    const size_t nparents = nchildren / p.ic;
+    for (int l = 0; l < ph; l++) { child_off += nchildren; nchildren /= ic; }
+    const size_t nparents = nchildren / ic;
     const size_t stride = (p.nlevels > 1) ? (size_t)nthreads : 0;
     for (size_t g = (size_t)bx * nthreads + tid; g < nparents; g += stride) {
-      const u32* ch = p.nodes + (child_off + g * p.ic) * 8;
+      const u32* ch = p.nodes + (child_off + g * ic) * 8;
       Sha256 h; h.init();
       u32 w[16];
-      for (u32 b = 0; b < p.ic / 2; b++) {
+      for (u32 b = 0; b < ic / 2; b++) {
         // two children = one 64-byte block, fetched as four 16-byte loads
         const uint4_t* c4 = reinterpret_cast<const uint4_t*>(ch + b * 16);
 #pragma unroll
@@ -252,8 +256,8 @@ struct InnerHashKernel {
       w[0] = 0x80000000u;
 #pragma unroll
       for (int i = 1; i < 15; i++) w[i] = 0;
-      if (p.ic == 2) { w[15] = 512u; h.compress(w); }
-      else { w[15] = p.ic * 256u; h.compress(w); }
+      w[15] = ic * 256u;  // message bits (ic * 32 bytes)
+      h.compress(w);
       uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + (child_off + nchildren + g) * 8);
       uint4_t o0, o1;
       o0.x = bswap32(h.st[0]); o0.y = bswap32(h.st[1]); o0.z = bswap32(h.st[2]); o0.w = bswap32(h.st[3]);
@@ -263,6 +267,9 @@ struct InnerHashKernel {
     }
   }
 };
+
+typedef InnerHashKernelT<0> InnerHashKernel;
+typedef InnerHashKernelT<2> InnerHashKernel2;
 
 // MerklePath extraction (src/merkle.rs:216-288), one thread per opened leaf.  Each job names a
 // tree (FRI codeword view, width = 1) and the device word holding the leaf index; writes

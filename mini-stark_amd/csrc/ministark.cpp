@@ -332,12 +332,14 @@ template <class F> struct Ctx : CtxBase {
         u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ts.ic) nl++;
         ip.nlevels = nl;
         next_bytes = (double)nchildren * 32 * 2;
-        CK(run<msmerkle::InnerHashKernel>(K_INNER_HASH, 1, 1, msmerkle::THREADS, 0, ip));
+        if (ts.ic == 2) CK(run<msmerkle::InnerHashKernel2>(K_INNER_HASH, 1, 1, msmerkle::THREADS, 0, ip));
+        else CK(run<msmerkle::InnerHashKernel>(K_INNER_HASH, 1, 1, msmerkle::THREADS, 0, ip));
         break;
       }
       ip.nlevels = 1;
       next_bytes = (double)nparents * (ts.ic * 32 + 32);
-      CK(run<msmerkle::InnerHashKernel>(K_INNER_HASH, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
+      if (ts.ic == 2) CK(run<msmerkle::InnerHashKernel2>(K_INNER_HASH, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
+      else CK(run<msmerkle::InnerHashKernel>(K_INNER_HASH, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
       child_off += nchildren; nchildren = nparents;
     }
     return 0;
