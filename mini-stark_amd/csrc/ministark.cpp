@@ -150,7 +150,7 @@ template <class F> struct Ctx : CtxBase {
   std::map<int, Plan*> plans;  // key = (log_n*4 + log_pad)*2 + inverse
   DevBuf ntt_scratch;
   int ntt_kmax = 9;            // largest tile (log2 rows) of a multi-pass plan; MS_NTT_KMAX overrides (tuning)
-  int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
+  int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1, ntt_fast = 1, ntt_virt_min_single = 1;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
 
   // log_pad: the input is zero beyond n >> log_pad
   int get_plan(int log_n, int log_pad, bool inverse, Plan** out) {
@@ -172,6 +172,12 @@ template <class F> struct Ctx : CtxBase {
         if (P < 2 && log_pad == 0) P = 2;
         if (P < 1) P = 1;
         if (P < bestP) { bestP = P; best_rho = lr; }
+      }
+      // measured on MI355X (tools/ntt_bench.py, r01): zero-padded transforms of 2^22..2^24 points are fastest as plain 3-pass plans
+      // on the compile-time specialised tiles (2^8-row tiles); smaller and larger ones with the virtual-pass plans
+      if (ntt_fast && bestP > 1 && (log_pad == 0 || (log_n >= 22 && log_n <= 24))) {
+        best_rho = 0; log_pad = 0;
+        bestP = (log_n + ntt_kmax - 1) / ntt_kmax; if (bestP < 2) bestP = 2;
       }
       pl->log_rho = best_rho; pl->log_r0 = log_pad + best_rho;
       const int m = log_n - pl->log_r0, P = bestP;
@@ -234,8 +240,23 @@ template <class F> struct Ctx : CtxBase {
     return 0;
   }
 
+  template <bool INV, int K, int TH>
+  int launch_fast(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
+    typedef msntt::PassKernelK<F, INV, K, TH> KK;
+    return run<KK>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, TH, KK::lds_bytes(), pp);
+  }
   template <bool INV>
   int launch_pass(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
+    // compile-time specialised tiles for the large transforms (no virtual pass, 16 columns)
+    if (ntt_fast && pp.log_C == msntt::TILE_LOG_C && pp.log_r0 == 0 && (pp.log_Rp == 0 || pp.log_Rp >= msntt::TILE_LOG_C)) {
+      switch (pp.log_r) {
+        case 6: return launch_fast<INV, 6, 256>(pp, tiles, batch);
+        case 7: return launch_fast<INV, 7, 256>(pp, tiles, batch);
+        case 8: return launch_fast<INV, 8, 256>(pp, tiles, batch);
+        case 9: return launch_fast<INV, 9, 512>(pp, tiles, batch);
+        default: break;
+      }
+    }
     const size_t lds = msntt::PassKernel<F, INV, 256>::lds_bytes(pp.log_r, pp.log_C, pp.log_Rp, pp.last != 0);
     if (ntt_th512 && pp.log_r >= 9 && pp.log_C == msntt::TILE_LOG_C)  // 8192-element tiles: 16 elements per thread
       return run<msntt::PassKernel<F, INV, 512>>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, 512, lds, pp);
@@ -383,6 +404,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_MAXPAD")) { int v = atoi(e); if (v >= 0 && v <= msntt::MAX_LOG_PAD) ntt_maxpad = v; }
     if (const char* e = getenv("MS_NTT_MAXRHO")) { int v = atoi(e); if (v >= 0 && v <= msntt::MAX_LOG_RHO) ntt_maxrho = v; }
     if (const char* e = getenv("MS_NTT_TH512")) ntt_th512 = atoi(e);
+    if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
     CK(msrt::set_device(dev));
     CK(msrt::stream_create(&own_stream));
     stream = own_stream;

@@ -43,13 +43,15 @@ constexpr int MAX_LOG_PAD = 3;      // zero-padding factor folded into the virtu
 constexpr int MAX_LOG_RHO = 2;      // ... times a real radix <= 4 over the non-zero input blocks
 
 // sub-round digit sizes for a tile of 2^K rows (top digit first)
-MS_HD int subround_count(int K) { return K <= 4 ? 1 : (K <= 8 ? 2 : 3); }
-MS_HD int subround_bits(int K, int s) {
+MS_HD constexpr int subround_count(int K) { return K <= 4 ? 1 : (K <= 8 ? 2 : 3); }
+MS_HD constexpr int subround_bits(int K, int s) {
   // K<=4: {K}; 5:{3,2} 6:{3,3} 7:{4,3} 8:{4,4}; 9:{3,3,3} 10:{4,3,3}
-  if (K <= 4) return K;
-  if (K <= 8) { int a = (K + 1) / 2; return s == 0 ? a : K - a; }
-  if (K == 9) return 3;
-  return s == 0 ? 4 : 3;
+  return K <= 4 ? K : (K <= 8 ? (s == 0 ? (K + 1) / 2 : K - (K + 1) / 2) : (K == 9 ? 3 : (s == 0 ? 4 : 3)));
+}
+MS_HD constexpr int subround_slo(int K, int s) {  // lowest row bit of sub-round s
+  int done = 0;
+  for (int t = 0; t <= s; t++) done += subround_bits(K, t);
+  return K - done;
 }
 
 template <class F> struct PassParams {
@@ -120,7 +122,7 @@ template <class F, bool INV, int B> MS_DEV void dif_regs(typename F::T (&x)[1 <<
 MS_HD constexpr int bitrev(int v, int bits) { int r = 0; for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i); return r; }
 
 // LDS row -> output digit index (and back) for the digit-reversed tile
-MS_HD int row_to_inew(int row, int K) {
+MS_HD constexpr int row_to_inew(int row, int K) {
   int S = subround_count(K), done = 0, inew = 0;
   for (int s = 0; s < S; s++) {
     int b = subround_bits(K, s);
@@ -130,7 +132,7 @@ MS_HD int row_to_inew(int row, int K) {
   }
   return inew;
 }
-MS_HD int inew_to_row(int inew, int K) {
+MS_HD constexpr int inew_to_row(int inew, int K) {
   int S = subround_count(K), done = 0, row = 0;
   for (int s = 0; s < S; s++) {
     int b = subround_bits(K, s);
@@ -325,6 +327,135 @@ template <class F, bool INV, int TH> struct PassKernel {
       if (do_scale) v = F::mul(v, p.scale);
       const size_t out = ((k_low << p.log_Rp) << K) + ((size_t)(f0 + cidx) & (size_t)Rp_m) + ((size_t)inew << p.log_Rp);
       dst[out] = v;
+    }
+  }
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// Compile-time specialised pass: K (log2 tile rows), 16 columns, TH threads, no virtual pass.
+// Same arithmetic and data movement as PassKernel, but every tile index, LDS address and output
+// offset is "per-thread base + compile-time constant": the pass is integer-VALU-issue bound on
+// MI355X (~4.4 cycles per wave-instruction), so the index arithmetic of the generic kernel
+// (~40% of its instructions) is what this removes.  Used for the large transforms.
+template <class F, bool INV, int K, int TH> struct PassKernelK {
+  typedef typename F::T T;
+  typedef PassParams<F> Params;
+  static constexpr int THREADS = TH;
+  static constexpr int C = 16, LC = 4, R = 1 << K, CP = C + 1;
+  static constexpr int RPT = TH / C;          // tile rows covered by one sweep of the workgroup
+  static constexpr int LRPT = (TH == 256) ? 4 : 5;
+  static constexpr int NIT = R / RPT;         // sweeps over the tile in the load / store phases
+  static constexpr int S = subround_count(K);
+  static_assert(K >= 5 && K <= 9 && (TH == 256 || TH == 512) && R >= RPT, "unsupported tile");
+
+  static MS_HD int nphases(const Params&) { return 2 + S; }
+  static MS_HD size_t lds_bytes() { return ((size_t)R * CP + R + NIT) * sizeof(T); }
+  static MS_HD bool applicable(const Params& p) {
+    return p.log_r == K && p.log_C == LC && p.log_r0 == 0 && (p.log_Rp == 0 || p.log_Rp >= LC);
+  }
+
+  static MS_DEV T tw_global(const Params& p, size_t e) {
+    T tw = p.tw_lo[e & (((size_t)1 << p.lo_bits) - 1)];
+    const size_t eh = e >> p.lo_bits;
+    if (eh) tw = F::mul(tw, p.tw_hi[eh]);
+    return tw;
+  }
+  // row bits of a sub-round work item g: B zero bits inserted at position SLO
+  template <int SLO, int B> static MS_HD constexpr int place(int g) { return ((g >> SLO) << (SLO + B)) | (g & ((1 << SLO) - 1)); }
+
+  template <int SR, int J> static MS_DEV void subround_items(int tid, T* tile, const T* w) {
+    constexpr int B = subround_bits(K, SR), SLO = subround_slo(K, SR), Q = 1 << SLO;
+    constexpr int GROUPS = R >> B;                 // work items per column
+    constexpr int NJ = (GROUPS + RPT - 1) / RPT;   // items per thread
+    constexpr int SH = K - SLO - B;                // twiddle index shift
+    const int cidx = tid & (C - 1), gb = tid >> LC;
+    if (GROUPS >= RPT || gb < GROUPS) {
+      constexpr int GJ = J * RPT;                  // compile-time part of the item index (disjoint bits from gb)
+      constexpr int ROW_J = place<SLO, B>(GJ), LO_J = GJ & (Q - 1);
+      T* base = tile + place<SLO, B>(gb) * CP + cidx;
+      T x[1 << B];
+#pragma unroll
+      for (int t = 0; t < (1 << B); t++) x[t] = base[(ROW_J + t * Q) * CP];
+      dif_regs<F, INV, B>(x, w, K);
+      if constexpr (SLO == 0) {
+#pragma unroll
+        for (int e = 0; e < (1 << B); e++) base[(ROW_J + e * Q) * CP] = x[bitrev(e, B)];
+      } else {
+        const int a = (gb & (Q - 1)) << SH;        // runtime part of lo << SH
+#pragma unroll
+        for (int e = 0; e < (1 << B); e++) {
+          T v = x[bitrev(e, B)];
+          if (e != 0) v = F::mul(v, w[e * a + ((e * LO_J) << SH)]);  // w_{Q 2^B}^(e*lo); lo == 0 multiplies by w[0] = 1
+          base[(ROW_J + e * Q) * CP] = v;
+        }
+      }
+    }
+    if constexpr (J + 1 < NJ) subround_items<SR, J + 1>(tid, tile, w);
+  }
+
+  template <int IT> static MS_DEV void load_rows(const T* src, size_t cs, T* trow) {
+    trow[IT * RPT * CP] = src[(size_t)(IT * RPT) * cs];
+    if constexpr (IT + 1 < NIT) load_rows<IT + 1>(src, cs, trow);
+  }
+  template <int IT> static MS_DEV void store_rows(const Params& p, const T* trow, T* out, T a, const T* tst, bool tw, bool do_scale) {
+    T v = trow[IT * RPT * CP];
+    if (tw) v = F::mul(v, F::mul(a, tst[IT]));
+    if (do_scale) v = F::mul(v, p.scale);
+    out[(size_t)row_to_inew(IT * RPT, K) << p.log_Rp] = v;
+    if constexpr (IT + 1 < NIT) store_rows<IT + 1>(p, trow, out, a, tst, tw, do_scale);
+  }
+
+  static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int, unsigned char* lds) {
+    T* tile = reinterpret_cast<T*>(lds);
+    T* w = tile + (size_t)R * CP;
+    T* tst = w + R;                                // [NIT] store twiddles of the sweep offsets
+    const size_t n = (size_t)1 << p.log_n, cs = n >> K, f0 = (size_t)bx << LC;
+    const int cidx = tid & (C - 1), rb = tid >> LC;
+    if (ph == 0) {
+      const T* src = p.src + (size_t)by * p.src_bstride + f0 + cidx + (size_t)rb * cs;
+      T* trow = tile + rb * CP + cidx;
+      if (p.n_in >= n) load_rows<0>(src, cs, trow);
+      else {
+        for (int it = 0; it < NIT; it++) {
+          const size_t a = f0 + cidx + (size_t)(rb + it * RPT) * cs;
+          trow[it * RPT * CP] = (a < p.n_in) ? src[(size_t)(it * RPT) * cs] : (T)0;
+        }
+      }
+      for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
+      if (!p.last && p.log_Rp && tid < NIT) {
+        const size_t k_low = f0 >> p.log_Rp;
+        tst[tid] = tw_global(p, ((size_t)row_to_inew(tid * RPT, K) * k_low) << p.log_Rp);
+      }
+      return;
+    }
+    if (ph <= S) {
+      if (ph == 1) subround_items<0, 0>(tid, tile, w);
+      if constexpr (S >= 2) { if (ph == 2) subround_items<1, 0>(tid, tile, w); }
+      if constexpr (S >= 3) { if (ph == 3) subround_items<2, 0>(tid, tile, w); }
+      return;
+    }
+    T* dst = p.dst + (size_t)by * p.dst_bstride;
+    const bool do_scale = p.scale != F::from_u64(1);
+    if (p.log_Rp) {
+      // columns stay columns: out = k_low*Rp*r + i_done + Rp*i_new, C-element runs
+      const size_t f = f0 + cidx, k_low = f0 >> p.log_Rp, i_done = f & (((size_t)1 << p.log_Rp) - 1);
+      const int inew_rb = row_to_inew(rb, K);
+      const bool tw = !p.last && k_low != 0;
+      T a = F::from_u64(1);
+      if (tw) a = tw_global(p, ((size_t)inew_rb * k_low) << p.log_Rp);
+      T* out = dst + ((k_low << p.log_Rp) << K) + i_done + ((size_t)inew_rb << p.log_Rp);
+      store_rows<0>(p, tile + rb * CP + cidx, out, a, tst, tw, do_scale);
+    } else {
+      // first pass: out = f*r + i_new, i_new fastest across lanes (transposed)
+      for (int idx = tid; idx < R * C; idx += TH) {
+        const int inew = idx & (R - 1), c2 = idx >> K;
+        const size_t f = f0 + c2;
+        T v = tile[inew_to_row(inew, K) * CP + c2];
+        if (!p.last) { const size_t e = (size_t)inew * f; if (e) v = F::mul(v, tw_global(p, e)); }
+        if (do_scale) v = F::mul(v, p.scale);
+        dst[(f << K) + inew] = v;
+      }
     }
   }
 };

@@ -29,7 +29,7 @@ def mk():
 
 
 @pytest.mark.parametrize("field", [0, 1])
-@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 7, 9, 10, 11, 13, 16])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_ntt(mk, field, log_n):
     pc.case_ntt(mk, field, log_n)
 
@@ -68,11 +68,12 @@ def test_error_codes(mk, field):
     pc.case_errors(mk, field)
 
 
-@pytest.mark.parametrize("kmax", ["5", "6", "7"])
-def test_ntt_virtual_pass_variants(kmax, monkeypatch):
+@pytest.mark.parametrize("kmax,fast", [("5", "0"), ("6", "0"), ("7", "0"), ("6", "1"), ("7", "1"), ("8", "1")])
+def test_ntt_virtual_pass_variants(kmax, fast, monkeypatch):
     """Small tiles force the multi-pass plans (virtual radix 8x{1,2,4} first pass, 2-4 real passes)
     that full-size transforms use on the GPU."""
     monkeypatch.setenv("MS_NTT_KMAX", kmax)
+    monkeypatch.setenv("MS_NTT_FAST", fast)  # 0: generic kernel incl. multi-pass virtual plans; 1: compile-time specialised tiles
     ctxs = {}
 
     def mk2(field, fresh=False):
