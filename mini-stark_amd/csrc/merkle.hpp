@@ -32,6 +32,22 @@ MS_HD u32 rotr32(u32 x, int n) {
 #endif
 }
 MS_HD u32 bswap32(u32 x) { return __builtin_bswap32(x); }
+// gfx950 v_bitop3_b32 (arbitrary 3-input bit function) issues in ~2.7 cycles per wave-instruction where v_bfi_b32 and
+// the other 3-source VOP3 ops take ~4.5 (tools/valu_rate.hip, profiles/r01_valu_issue_rate.txt).
+MS_HD u32 ch3(u32 e, u32 f, u32 g) {  // e ? f : g
+#if defined(__HIP_DEVICE_COMPILE__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
+  return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA);
+#else
+  return g ^ (e & (f ^ g));
+#endif
+}
+MS_HD u32 maj3(u32 a, u32 b, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+#else
+  return (a & b) | (c & (a | b));
+#endif
+}
 // a ^ b ^ c in one instruction on gfx950 (v_bitop3_b32, truth table 0x96)
 MS_HD u32 xor3(u32 a, u32 b, u32 c) {
 #if defined(__HIP_DEVICE_COMPILE__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
@@ -68,10 +84,10 @@ struct Sha256 {
         w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
       }
       u32 S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
-      u32 ch = g ^ (e & (f ^ g));
+      u32 ch = ch3(e, f, g);
       u32 t1 = h + S1 + ch + K[i] + w[i & 15];
       u32 S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
-      u32 mj = (a & b) | (c & (a | b));
+      u32 mj = maj3(a, b, c);
       u32 t2 = S0 + mj;
       h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }

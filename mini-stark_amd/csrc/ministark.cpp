@@ -103,14 +103,15 @@ template <class F> struct Ctx : CtxBase {
   // ---- optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
   enum { K_NTT_PASS, K_SCALE_POW, K_LEAF_HASH, K_INNER_HASH, K_TRANSPOSE, K_IO, K_LINCOMB, K_MIX, K_EVAL, K_EVAL_REDUCE, K_FOLD,
          K_SUFFIX_HORNER, K_DEGREE, K_FIND_FIRST, K_PATH, K_QUERY_POINTS, K_COUNT };
-  struct ProfRec { int kid; msrt::Event* a; msrt::Event* b; double bytes; };
+  struct ProfRec { int kid, sub; msrt::Event* a; msrt::Event* b; double bytes; };
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
   double next_bytes = 0;  // algorithmic bytes attributed to the next launch
+  int next_sub = 0;       // NTT pass variant of the next launch: K | 16*(TH==512) | 32*generic | 64*inverse
   template <class K> int run(int kid, unsigned gx, unsigned gy, int threads, size_t lds, const typename K::Params& p) {
     if (gx == 0 || gy == 0) return 0;
     if (!prof_on) return msrt::launch<K>(stream, gx, gy, threads, lds, p);
-    ProfRec r; r.kid = kid; r.bytes = next_bytes; next_bytes = 0;
+    ProfRec r; r.kid = kid; r.sub = next_sub; r.bytes = next_bytes; next_bytes = 0; next_sub = 0;
     if (msrt::event_create(&r.a) || msrt::event_create(&r.b)) return 1;
     msrt::event_record(r.a, stream);
     int e = msrt::launch<K>(stream, gx, gy, threads, lds, p);
@@ -124,9 +125,11 @@ template <class F> struct Ctx : CtxBase {
                                          "fold", "suffix_horner", "degree", "find_first", "merkle_path", "query_points"};
     msrt::sync(stream);
     double ms[K_COUNT] = {0}, by[K_COUNT] = {0}; unsigned long long cnt[K_COUNT] = {0};
+    std::map<int, double> sub_ms, sub_by; std::map<int, unsigned long long> sub_cnt;
     for (auto& r : prof_recs) {
       float t = 0.f; msrt::event_elapsed_ms(&t, r.a, r.b);
       ms[r.kid] += t; by[r.kid] += r.bytes; cnt[r.kid]++;
+      if (r.kid == K_NTT_PASS) { sub_ms[r.sub] += t; sub_by[r.sub] += r.bytes; sub_cnt[r.sub]++; }
       msrt::event_destroy(r.a); msrt::event_destroy(r.b);
     }
     prof_recs.clear(); prof_on = false;
@@ -136,7 +139,18 @@ template <class F> struct Ctx : CtxBase {
       snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"alg_bytes\": %.0f}", k ? ", " : "", names[k], cnt[k], ms[k], by[k]);
       j += buf;
     }
-    j += "}";
+    // per template instance of the NTT pass kernel (matches the kernel names rocprofv3 reports)
+    j += ", \"ntt_pass_variants\": {";
+    bool first = true;
+    for (auto& kv : sub_ms) {
+      const int sub = kv.first; char name[160], buf[320];
+      const char* fld = F::ID == 0 ? "GL" : "BB";
+      if (sub & 32) snprintf(name, sizeof name, "msntt::PassKernel<%s, %s, %d>", fld, (sub & 64) ? "true" : "false", (sub & 16) ? 512 : 256);
+      else snprintf(name, sizeof name, "msntt::PassKernelK<%s, %s, %d, %d>", fld, (sub & 64) ? "true" : "false", sub & 15, (sub & 16) ? 512 : 256);
+      snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"alg_bytes\": %.0f}", first ? "" : ", ", name, sub_cnt[sub], kv.second, sub_by[sub]);
+      j += buf; first = false;
+    }
+    j += "}}";
     if (out && cap) { size_t n = j.size() < cap - 1 ? j.size() : cap - 1; memcpy(out, j.data(), n); out[n] = 0; }
     return 0;
   }
@@ -243,6 +257,7 @@ template <class F> struct Ctx : CtxBase {
   template <bool INV, int K, int TH>
   int launch_fast(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
     typedef msntt::PassKernelK<F, INV, K, TH> KK;
+    next_sub = K | (TH == 512 ? 16 : 0) | (INV ? 64 : 0);
     return run<KK>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, TH, KK::lds_bytes(), pp);
   }
   template <bool INV>
@@ -258,8 +273,11 @@ template <class F> struct Ctx : CtxBase {
       }
     }
     const size_t lds = msntt::PassKernel<F, INV, 256>::lds_bytes(pp.log_r, pp.log_C, pp.log_Rp, pp.last != 0);
-    if (ntt_th512 && pp.log_r >= 9 && pp.log_C == msntt::TILE_LOG_C)  // 8192-element tiles: 16 elements per thread
+    next_sub = 32 | (INV ? 64 : 0);
+    if (ntt_th512 && pp.log_r >= 9 && pp.log_C == msntt::TILE_LOG_C) {  // 8192-element tiles: 16 elements per thread
+      next_sub |= 16;
       return run<msntt::PassKernel<F, INV, 512>>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, 512, lds, pp);
+    }
     return run<msntt::PassKernel<F, INV, 256>>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, 256, lds, pp);
   }
 

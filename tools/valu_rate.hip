@@ -11,16 +11,16 @@ template <int OP> __global__ void k(uint32_t* out, uint32_t seed) {
   for (int it = 0; it < ITERS; it++) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {  // 8 independent chains per thread
-      if (OP == 0) a[i] = a[i] ^ b;                                                    // v_xor_b32
-      if (OP == 1) a[i] = __builtin_amdgcn_alignbit(a[i], a[i], 7);                    // v_alignbit_b32 (rotate)
+      if (OP == 0) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(b));
+      if (OP == 1) asm volatile("v_alignbit_b32 %0, %1, %1, 7" : "=v"(a[i]) : "v"(a[i]));
       if (OP == 2) asm volatile("v_lshl_or_b32 %0, %1, 25, %2" : "=v"(a[i]) : "v"(a[i]), "v"(b));  // v_lshl_or_b32
-      if (OP == 3) a[i] = a[i] + b + c;                                                // v_add3_u32
+      if (OP == 3) asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(b), "v"(c));
       if (OP == 4) asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(b), "v"(c));
-      if (OP == 5) a[i] = __builtin_amdgcn_bitop3_b32(a[i], b, c, 0x96);               // v_bitop3_b32
-      if (OP == 6) a[i] = a[i] * b;                                                    // v_mul_lo_u32
-      if (OP == 7) a[i] = __umulhi(a[i], b);                                           // v_mul_hi_u32
+      if (OP == 5) asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(a[i]) : "v"(a[i]), "v"(b), "v"(c));
+      if (OP == 6) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(b));
+      if (OP == 7) asm volatile("v_mul_hi_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(b));
       if (OP == 8) { uint64_t t = (uint64_t)a[i] * b + c; a[i] = (uint32_t)(t >> 32) ^ (uint32_t)t; }  // v_mad_u64_u32 (+xor)
-      if (OP == 9) a[i] = (a[i] >> 7) + b;                                             // shift + add
+      if (OP == 9) asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(b));
       if (OP == 10) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(b), "v"(c));
       if (OP == 11) asm volatile("v_alignbyte_b32 %0, %1, %2, 1" : "=v"(a[i]) : "v"(a[i]), "v"(b));
     }
@@ -46,6 +46,6 @@ int main() {
   uint32_t* d; hipMalloc(&d, 256 * 8 * 256 * 4);
   run<0>("v_xor", d, 0); run<1>("v_alignbit", d, 0); run<2>("v_lshl_or", d, 0); run<3>("v_add3", d, 0); run<4>("v_bfi", d, 0);
   run<5>("v_bitop3", d, 0); run<6>("v_mul_lo_u32", d, 0); run<7>("v_mul_hi_u32", d, 0); run<8>("v_mad_u64_u32+xor", d, 1);
-  run<9>("lshr+add", d, 1); run<10>("v_perm", d, 0); run<11>("v_alignbyte", d, 0);
+  run<9>("v_add_u32", d, 0); run<10>("v_perm", d, 0); run<11>("v_alignbyte", d, 0);
   return 0;
 }
