@@ -51,6 +51,8 @@ typedef enum {
 
 /* flags for ms_create */
 #define MS_FLAG_ZERO_DISPLAY_EMPTY 0x1u /* ark-ff Display prints ZERO as "" (default behaviour of ark-ff 0.5.0) */
+#define MS_FLAG_TRACE_MONT64 0x2u       /* ms_trace_commit* input is arkworks memory: Montgomery form x*2^64 mod p, one u64 limb
+                                          (`Fp<MontBackend<_,1>,1>`, src/field.rs:47,76); everything else stays canonical */
 #define MS_FLAGS_DEFAULT MS_FLAG_ZERO_DISPLAY_EMPTY
 
 /* ---- context ------------------------------------------------------------ */

@@ -92,7 +92,7 @@ template <class F> struct Ctx : CtxBase {
   static constexpr int E = F::EXT;
   typedef Ext<F, E> XE;
 
-  int device = 0, zae = 1;
+  int device = 0, zae = 1, trace_mont = 0;
   msrt::Stream* own_stream = nullptr;
   msrt::Stream* stream = nullptr;
   void* pinned = nullptr; size_t pinned_cap = 0;
@@ -417,7 +417,7 @@ template <class F> struct Ctx : CtxBase {
   }
 
   int init(int dev, u32 flags) {
-    device = dev; zae = (flags & MS_FLAG_ZERO_DISPLAY_EMPTY) ? 1 : 0;
+    device = dev; zae = (flags & MS_FLAG_ZERO_DISPLAY_EMPTY) ? 1 : 0; trace_mont = (flags & MS_FLAG_TRACE_MONT64) ? 1 : 0;
     if (const char* e = getenv("MS_NTT_KMAX")) { int v = atoi(e); if (v >= 5 && v <= msntt::MAX_LOG_R) ntt_kmax = v; }
     if (const char* e = getenv("MS_NTT_MAXPAD")) { int v = atoi(e); if (v >= 0 && v <= msntt::MAX_LOG_PAD) ntt_maxpad = v; }
     if (const char* e = getenv("MS_NTT_MAXRHO")) { int v = atoi(e); if (v >= 0 && v <= msntt::MAX_LOG_RHO) ntt_maxrho = v; }
@@ -483,7 +483,9 @@ template <class F> struct Ctx : CtxBase {
       dsrc = d_trace.as<u64>();
     }
     RQ(ensure_polys(w + 1));
-    typename mspoly::TransposeInKernel<F>::Params tp{dsrc, d_polys.as<T>(), N, w, N};
+    // 2^-64 mod p: arkworks stores Montgomery representatives (R = 2^64 for the one-limb Fp of both fields)
+    const T rinv = f_inv<F>(F::from_u64((u64)(((unsigned __int128)1 << 64) % F::P)));
+    typename mspoly::TransposeInKernel<F>::Params tp{dsrc, d_polys.as<T>(), N, w, N, rinv, trace_mont};
     CK(run<mspoly::TransposeInKernel<F>>(K_TRANSPOSE, grid1(N * w, mspoly::THREADS), 1, mspoly::THREADS, 0, tp));
     // element f of trace.get_data() = column f % w, row f / w of the column-major copy
     RQ((tree_build<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));

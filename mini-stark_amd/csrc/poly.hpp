@@ -23,13 +23,15 @@ constexpr int THREADS = 256;
 template <class F> struct TransposeInKernel {
   typedef typename F::T T;
   static constexpr int THREADS = mspoly::THREADS;
-  struct Params { const u64* src; T* dst; size_t N, w, dst_stride; };
+  struct Params { const u64* src; T* dst; size_t N, w, dst_stride; T rinv; int mont; /* mont: src holds x*2^64 mod p; rinv = 2^-64 mod p */ };
   static MS_HD int nphases(const Params&) { return 1; }
   static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
     const size_t f = (size_t)bx * nthreads + tid;
     if (f >= p.N * p.w) return;
     const size_t row = f / p.w, col = f - row * p.w;
-    p.dst[col * p.dst_stride + row] = F::from_u64(p.src[f]);
+    T v = F::from_u64(p.src[f]);
+    if (p.mont) v = F::mul(v, p.rinv);
+    p.dst[col * p.dst_stride + row] = v;
   }
 };
 // plain widening / narrowing copies between the u64 ABI and device storage

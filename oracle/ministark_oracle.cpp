@@ -495,6 +495,7 @@ struct SessionBase {
   virtual int mix(u64 r) = 0;
   virtual int validity_read(u64* out) = 0;
   virtual int eval_ext(const u64* z, int q, u64* out) = 0;
+  virtual int verify_ood(u64 r, const u64* z, int q, const u64* evals) = 0;
   virtual int fri_begin(size_t blowup, size_t rounds, u8 root0[32]) = 0;
   virtual int fri_deep(const u64* z, u64* B) = 0;
   virtual int fri_fold_commit(const u64* alpha, u8 root[32]) = 0;
@@ -631,6 +632,34 @@ template <class F, int E> struct Session : SessionBase {
       }
     }
     return OR_OK;
+  }
+
+  // src/starks.rs:204-225 — the DEEP-ALI half of Stark::verify, against THIS session's constraint polynomials
+  // (the verifier derives them itself: tests/e2e_goldilocks.rs:101-102).  evals[t] = c constrain_queries then the
+  // validity_query.  Returns 1 on accept, 0 on reject.
+  int verify_ood(u64 r, const u64* z, int q, const u64* evals) override {
+    if (polys.empty()) return OR_ERR_STATE;
+    const size_t c = polys.size();
+    for (int t = 0; t < q; t++) {
+      Ext<F, E> x; for (int k = 0; k < E; k++) x.c[k] = z[t * E + k];
+      Poly<F, E> c_x;  // starks.rs:212
+      u64 ri = 1;
+      for (size_t i = 0; i < c; i++) {
+        Poly<F, E> p = extend_poly(polys[i]);
+        Ext<F, E> v = p_eval<F, E>(p, x);
+        for (int k = 0; k < E; k++) if (v.c[k] != evals[(t * (c + 1) + i) * E + k]) return 0;  // starks.rs:216
+        if (c_x.size() < p.size()) c_x.resize(p.size(), e_zero<F, E>());
+        for (size_t j = 0; j < p.size(); j++) c_x[j] = e_add<F, E>(c_x[j], e_mul_base<F, E>(p[j], ri));  // starks.rs:217
+        ri = F::mul(ri, r);
+      }
+      p_trim<F, E>(c_x);
+      // starks.rs:220-221: divide_by_vanishing_poly returns (quotient, remainder); the name `rest` binds the QUOTIENT,
+      // which must be zero, and `quotient` binds the remainder (quirk Q1)
+      if (c_x.size() > N) return 0;
+      Ext<F, E> ev = p_eval<F, E>(c_x, x);  // starks.rs:223
+      for (int k = 0; k < E; k++) if (ev.c[k] != evals[(t * (c + 1) + c) * E + k]) return 0;  // starks.rs:224
+    }
+    return 1;
   }
 
   // fri.rs:314-352
@@ -949,6 +978,7 @@ int or_lde_nodes_read(void* s, u8* out) { return ((SessionBase*)s)->lde_nodes_re
 int or_mix(void* s, u64 r) { return ((SessionBase*)s)->mix(r); }
 int or_validity_read(void* s, u64* out) { return ((SessionBase*)s)->validity_read(out); }
 int or_eval_ext(void* s, const u64* z, int q, u64* out) { return ((SessionBase*)s)->eval_ext(z, q, out); }
+int or_verify_ood(void* s, u64 r, const u64* z, int q, const u64* evals) { return ((SessionBase*)s)->verify_ood(r, z, q, evals); }
 int or_fri_begin(void* s, size_t blowup, size_t rounds, u8 root0[32]) { return ((SessionBase*)s)->fri_begin(blowup, rounds, root0); }
 int or_fri_deep(void* s, const u64* z, u64* B) { return ((SessionBase*)s)->fri_deep(z, B); }
 int or_fri_fold_commit(void* s, const u64* alpha, u8 root[32]) { return ((SessionBase*)s)->fri_fold_commit(alpha, root); }

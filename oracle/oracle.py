@@ -247,6 +247,12 @@ class Session:
         rc = self.L.or_eval_ext(self.h, zp, C.c_int(q), out.ctypes.data_as(u64p))
         return rc, out
 
+    def verify_ood(self, r, z, evals):
+        """src/starks.rs:204-225 against this session's polynomials; evals: [q][c+1][E]."""
+        z, zp = _u64(z)
+        ev, ep = _u64(evals)
+        return int(self.L.or_verify_ood(self.h, C.c_uint64(r), zp, C.c_int(z.size // self.e), ep))
+
     def fri_begin(self, blowup, rounds):
         root = (C.c_uint8 * 32)()
         rc = self.L.or_fri_begin(self.h, C.c_size_t(blowup), C.c_size_t(rounds), root)

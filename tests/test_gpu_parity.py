@@ -132,3 +132,30 @@ def test_host_mirror_on_gpu(mk, field, steps, blowup):
     import test_host_mirror as thm
     build_host_library()
     thm.check_pair(mk(field), steps, blowup)
+
+
+def test_full_size_bit_exact_vs_oracle(mk):
+    """BASELINE.json configs[1] at full size (2^20 rows, blowup 8, Goldilocks): every commitment, OOD value, FRI round
+    and the serialised FRI proof (~64 MiB) bit-exact against the single-threaded CPU oracle (~1 min of host time)."""
+    pc.case_prove(mk, 0, 20, 8, nq_fri=0, read_big=False)
+
+
+def test_full_size_ood_values_verify(mk):
+    """DEEP-ALI half of Stark::verify (src/starks.rs:204-225, oracle restatement) on a full-size GPU proof."""
+    from mini_stark_amd.host import HostStark, build_host_library
+    from mini_stark_amd.stark import fibonacci_air
+    build_host_library()
+    for field in (0, 1):
+        ctx = mk(field)
+        steps = (1 << 20) - 1
+        tt = fibonacci_air(ctx, steps)
+        hs = HostStark(ctx, 20, 8, steps, tt.constrain_number())
+        proof = hs.prove(tt, read_fri_proof=False)
+        ch = [int(v) for v in hs.last_challenges]
+        o = orc.Session(field)
+        assert o.trace_commit(tt.data, tt.constrain_number()) == (0, proof.trace_commit)   # CPU hashes the 2^20 x 3 trace too
+        assert o.interpolate() == 0
+        for sc, idx in tt.transitions:
+            assert o.polys_lincomb(sc, idx) == 0
+        ev = np.concatenate([proof.constrain_queries, proof.validity_queries[:, None, :]], axis=1)
+        assert o.verify_ood(ch[1], ch[2:2 + hs.constrain_queries * ctx.e], ev) == 1

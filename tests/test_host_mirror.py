@@ -64,3 +64,35 @@ def test_low_security_bits_rejected(emu):
         HostStark(ctx, 19, 2, 9, 6)  # starks.rs:341-346 should_panic
     with pytest.raises(ms.MsError):
         StarkConfig(ctx, 1, 4, 128, 6)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_stark_verify_deep_ali_and_mont64_input(emu, field):
+    """(i) The OOD values of a proof satisfy the DEEP-ALI half of Stark::verify (src/starks.rs:204-225) restated in
+    the oracle, and a tampered value is rejected.  (ii) A trace handed over in arkworks' Montgomery form
+    (MS_FLAG_TRACE_MONT64) gives the same proof as the canonical one."""
+    from common import MODULUS
+    p = MODULUS[field]
+    ctx = ms.Context(field, lib_path=emu)
+    steps, blowup = 63, 8
+    tt = fibonacci_air(ctx, steps)
+    hs = HostStark(ctx, 20, blowup, steps, tt.constrain_number())
+    proof = hs.prove(tt)
+    ch = [int(v) for v in hs.last_challenges]
+    r, z = ch[1], ch[2:2 + hs.constrain_queries * ctx.e]
+    o = orc.Session(field)
+    assert o.trace_commit(tt.data, tt.constrain_number())[0] == 0 and o.interpolate() == 0
+    for sc, idx in tt.transitions:
+        assert o.polys_lincomb(sc, idx) == 0
+    ev = np.concatenate([proof.constrain_queries, proof.validity_queries[:, None, :]], axis=1)
+    assert o.verify_ood(r, z, ev) == 1
+    bad = ev.copy(); bad[0, 2, 0] ^= np.uint64(1)
+    assert o.verify_ood(r, z, bad) == 0
+    assert o.verify_ood((r + 1) % p, z, ev) == 0
+    # Montgomery-form input
+    mctx = ms.Context(field, flags=ms.FLAG_ZERO_DISPLAY_EMPTY | ms.FLAG_TRACE_MONT64, lib_path=emu)
+    mt = fibonacci_air(mctx, steps)
+    R = (1 << 64) % p
+    mt.data[:] = np.array([[int(v) * R % p for v in row] for row in tt.data], dtype=np.uint64)
+    mp = HostStark(mctx, 20, blowup, steps, mt.constrain_number()).prove(mt)
+    assert mp.arthur == proof.arthur and mp.fri_proof.blob == proof.fri_proof.blob and mp.trace_commit == proof.trace_commit
