@@ -54,6 +54,7 @@ struct CtxBase {
   std::string err;
   virtual ~CtxBase() {}
   virtual int ext_degree() const = 0;
+  virtual void bind_device() const = 0;  // HIP's current device is per host thread: every entry point binds the context's device
   virtual int set_stream(void* s) = 0;
   virtual int synchronize() = 0;
   virtual int trace_commit(const u64* trace, bool on_device, size_t N, size_t w, size_t lpn, u8* root) = 0;
@@ -440,6 +441,7 @@ template <class F> struct Ctx : CtxBase {
     if (own_stream) msrt::stream_destroy(own_stream);
   }
   int ext_degree() const override { return E; }
+  void bind_device() const override { msrt::set_device(device); }
   int set_stream(void* s) override { stream = s ? reinterpret_cast<msrt::Stream*>(s) : own_stream; return 0; }
   int synchronize() override { CK(msrt::sync(stream)); return 0; }
 
@@ -1043,11 +1045,11 @@ int ms_create(ms_ctx** out, int device, ms_field field, uint32_t flags) {
   else return MS_ERR_ARG;
   return MS_OK;
 }
-void ms_destroy(ms_ctx* ctx) { delete B(ctx); }
+void ms_destroy(ms_ctx* ctx) { if (ctx) { B(ctx)->bind_device(); delete B(ctx); } }
 const char* ms_last_error(const ms_ctx* ctx) { return ctx ? B(ctx)->err.c_str() : "null context"; }
 int ms_ext_degree(const ms_ctx* ctx) { return ctx ? B(ctx)->ext_degree() : MS_ERR_ARG; }
 int ms_set_stream(ms_ctx* ctx, void* s) { return ctx ? B(ctx)->set_stream(s) : MS_ERR_ARG; }
-int ms_synchronize(ms_ctx* ctx) { return ctx ? B(ctx)->synchronize() : MS_ERR_ARG; }
+int ms_synchronize(ms_ctx* ctx) { if (!ctx) return MS_ERR_ARG; B(ctx)->bind_device(); return B(ctx)->synchronize(); }
 
 int ms_is_power_of_two(uint64_t n) { return is_pow2(n) ? 1 : 0; }
 long ms_logarithm_of_two_k(uint64_t n, uint64_t base) { return log_two_k(n, base); }
@@ -1074,7 +1076,7 @@ uint64_t ms_root_of_unity(ms_field f, uint64_t n) {
   return lg <= BB::TWO_ADICITY ? BB::to_u64(f_root_of_unity<BB>(lg)) : 0;
 }
 
-#define CTX_OR_FAIL if (!ctx) return MS_ERR_ARG
+#define CTX_OR_FAIL if (!ctx) return MS_ERR_ARG; B(ctx)->bind_device()
 int ms_trace_commit(ms_ctx* ctx, const uint64_t* t, size_t N, size_t w, size_t lpn, uint8_t root[32]) { CTX_OR_FAIL; return B(ctx)->trace_commit(t, false, N, w, lpn, root); }
 int ms_trace_commit_device(ms_ctx* ctx, const void* t, size_t N, size_t w, size_t lpn, uint8_t root[32]) { CTX_OR_FAIL; return B(ctx)->trace_commit(reinterpret_cast<const u64*>(t), true, N, w, lpn, root); }
 int ms_interpolate(ms_ctx* ctx) { CTX_OR_FAIL; return B(ctx)->interpolate(); }

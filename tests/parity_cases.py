@@ -151,3 +151,66 @@ def case_errors(mk, field):
     assert ctx.merkle_commit(np.zeros(0, dtype=np.uint64), 1, 2, 2)[0] == ms.ERR_SHAPE
     assert ctx.num_queries(1, 4, 128)[0] == ms.ERR_SHAPE          # starks.rs:341-346
     assert ctx.num_queries(20, 4, 129) == (0, 1, 3) if field == 0 else True
+
+
+def case_prove_wide(mk, field, log_n=8, w=64, blowup=8, seed=5):
+    """BASELINE configs[4] shape: 64 trace columns + 64 transition polynomials (c = 128), random trace; the transition
+    polynomials are linear (quirk Q1: degree-3 constraints are not expressible in the reference)."""
+    p, e = MODULUS[field], EXT[field]
+    N = 1 << log_n
+    trace = rand_field(field, (N, w), seed=seed)
+    rng = SplitMix64(seed)
+    combos = [([rng.nonzero(p), rng.field(p), p - 1], [j, (j + 1) % w, (j + 7) % w]) for j in range(w)]
+    outs = []
+    for sess in (mk(field), orc.Session(field)):
+        r2 = SplitMix64(seed + 1)
+        o = []
+        rc, root = sess.trace_commit(trace, 2 * w)
+        assert rc == 0
+        o.append(root)
+        assert sess.interpolate() == 0
+        for sc, idx in combos:
+            assert sess.polys_lincomb(sc, idx) == 0
+        assert sess.polys_count() == 2 * w
+        rc, root = sess.lde_commit(blowup, r2.nonzero(p), 2 * w)
+        assert rc == 0
+        o.append(root)
+        assert sess.mix(r2.field(p)) == 0
+        rc, ev = sess.eval_ext(np.array([r2.field(p) for _ in range(e)], dtype=np.uint64))
+        assert rc == 0
+        o.append(ev.tolist())
+        rounds = log_n + 3
+        rc, root = sess.fri_begin(blowup, rounds)
+        assert rc == 0
+        o.append(root)
+        for _ in range(1, rounds):
+            rc, B = sess.fri_deep([r2.field(p) for _ in range(e)])
+            assert rc == 0
+            rc, root = sess.fri_fold_commit([r2.field(p) for _ in range(e)])
+            assert rc == 0
+            o.append((B.tolist(), root))
+        rc, proof = sess.fri_query([r2.next()])
+        assert rc == 0
+        o.append(proof)
+        outs.append(o)
+    assert outs[0] == outs[1]
+
+
+def case_general_closure(mk, field, log_n=6):
+    """A transition closure evaluated on the HOST (air.rs:130-134: closures see coefficient vectors): read the trace
+    polynomials back, combine them, ms_polys_append — must equal the on-device ms_polys_lincomb of the same closure."""
+    p = MODULUS[field]
+    N = 1 << log_n
+    trace = fibonacci_trace(field, N)
+    omega = orc.root_of_unity(field, N)
+    a, b = mk(field), mk(field, fresh=True)
+    for s in (a, b):
+        assert s.trace_commit(trace, 6)[0] == 0 and s.interpolate() == 0
+    assert a.polys_lincomb([omega, p - 1], [0, 1]) == 0
+    P0, P1 = [int(v) for v in b.poly_read(0)], [int(v) for v in b.poly_read(1)]
+    host = np.array([(omega * x - y) % p for x, y in zip(P0, P1)], dtype=np.uint64)
+    assert b.polys_append(host) == 0
+    assert (a.poly_read(3) == b.poly_read(3)).all()
+    assert a.lde_commit(4, 3, 4)[1] == b.lde_commit(4, 3, 4)[1]
+    import mini_stark_amd as ms
+    assert b.polys_append(np.zeros(N + 1, dtype=np.uint64)) == ms.ERR_SHAPE   # more than N coefficients: starks.rs:118-119 would panic

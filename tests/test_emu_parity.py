@@ -87,3 +87,26 @@ def test_ntt_virtual_pass_variants(kmax, fast, monkeypatch):
         pc.case_ntt(mk2, field, 16, batch=1)
     pc.case_prove(mk2, 0, 10, 8, read_big=False)
     pc.case_prove(mk2, 1, 9, 8, read_big=False)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_wide_air_shape(mk, field):
+    pc.case_prove_wide(mk, field, log_n=6, w=64)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_general_closure_path(mk, field):
+    pc.case_general_closure(mk, field)
+
+
+def test_trace_commit_device_pointer(mk):
+    """ms_trace_commit_device: same result as the host-pointer entry (in the emulation build a device pointer is a
+    host pointer; on the GPU bench.py passes a torch tensor's data_ptr)."""
+    import numpy as np
+    from common import fibonacci_trace
+    ctx = mk(0)
+    t = np.ascontiguousarray(fibonacci_trace(0, 64))
+    rc1, r1 = ctx.trace_commit(t, 6)
+    rc2, r2 = ctx.trace_commit_device(t.ctypes.data, 64, 3, 6)
+    assert rc1 == 0 and rc2 == 0 and r1 == r2
+    assert ctx.interpolate() == 0

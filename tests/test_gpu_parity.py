@@ -159,3 +159,13 @@ def test_full_size_ood_values_verify(mk):
             assert o.polys_lincomb(sc, idx) == 0
         ev = np.concatenate([proof.constrain_queries, proof.validity_queries[:, None, :]], axis=1)
         assert o.verify_ood(ch[1], ch[2:2 + hs.constrain_queries * ctx.e], ev) == 1
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_wide_air_shape(mk, field):
+    pc.case_prove_wide(mk, field, log_n=10, w=64)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_general_closure_path(mk, field):
+    pc.case_general_closure(mk, field)
