@@ -9,13 +9,14 @@
 // prints as the empty string when zero_as_empty=1), and
 // "QuadExtField(c0 + c1 * u)" (nested) for the extension towers.
 //
-// One thread owns one digest.  The message is produced as a byte stream
-// (decimal conversion in registers) into a 16-word block buffer that lives in
-// LDS word-interleaved across the workgroup (bank-conflict free), and is
-// compressed every 64 bytes; SHA-256 state and message schedule stay in
-// registers.  Both passes are 32-bit-ALU bound, not HBM bound: algorithmic
-// traffic is lpn*E*sizeof(T) + 32 bytes per leaf group and 96 bytes per inner
-// node against ~2-3 compressions each.
+// One thread owns one digest.  An element becomes 4-digit decimal chunks packed as
+// big-endian ASCII words (no per-digit work), appended through a 64-bit funnel
+// into a per-thread ring of message words that lives in LDS word-interleaved
+// across the workgroup (bank-conflict free); complete 64-byte blocks are
+// compressed with SHA-256 state and schedule in registers.  Both passes are
+// integer-VALU-issue bound, not HBM bound: algorithmic traffic is
+// lpn*E*sizeof(T) + 32 bytes per leaf group and 96 bytes per inner node against
+// 2-3 compressions (~1440 instructions each).
 #pragma once
 #include "field.hpp"
 
