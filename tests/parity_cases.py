@@ -116,9 +116,13 @@ def drive(sess, field, trace, blowup, nq_fri, seed, rounds=None, q_ood=2, read_b
     return out
 
 
-def case_prove(mk, field, log_n, blowup, nq_fri=2, seed=77, read_big=True):
+def case_prove(mk, field, log_n, blowup, nq_fri=2, seed=77, read_big=True, steps=None):
     N = 1 << log_n
-    trace = fibonacci_trace_fast(field, N)
+    if steps is None:
+        trace = fibonacci_trace_fast(field, N)
+    else:  # several padding rows (air.rs:79-83): steps + 1 <= N, steps >= N / 2
+        from mini_stark_amd.synthetic import fibonacci_rows
+        trace = fibonacci_rows(MODULUS[field], N, steps, secret_b=seed, pad_seed=seed * 3 + 1)
     a = drive(mk(field), field, trace, blowup, nq_fri, seed, read_big=read_big)
     b = drive(orc.Session(field), field, trace, blowup, nq_fri, seed, read_big=read_big)
     assert len(a) == len(b)

@@ -110,3 +110,18 @@ def test_trace_commit_device_pointer(mk):
     rc2, r2 = ctx.trace_commit_device(t.ctypes.data, 64, 3, 6)
     assert rc1 == 0 and rc2 == 0 and r1 == r2
     assert ctx.interpolate() == 0
+
+
+def test_prove_randomised_shapes(mk):
+    """Differential fuzz: random step counts (several padding rows), blowups, query counts, seeds, both fields."""
+    import random
+    rnd = random.Random(20261003)
+    for _ in range(12):
+        field = rnd.randrange(2)
+        log_n = rnd.randrange(2, 9)
+        N = 1 << log_n
+        steps = rnd.randrange(N // 2, N)          # Radix2EvaluationDomain::new(steps + 1) == N
+        blowup = rnd.choice([2, 4, 8, 16])
+        if log_n + blowup.bit_length() - 1 > 14:
+            blowup = 2
+        pc.case_prove(mk, field, log_n, blowup, nq_fri=rnd.randrange(0, 4), seed=rnd.randrange(1, 1 << 30), read_big=(log_n <= 6), steps=steps)
