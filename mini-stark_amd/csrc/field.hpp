@@ -65,7 +65,16 @@ struct BB {
   static MS_HD T add(T a, T b) { u32 s = a + b; if (s >= (u32)P) s -= (u32)P; return s; }
   static MS_HD T sub(T a, T b) { return a >= b ? a - b : a + (u32)P - b; }
   static MS_HD T neg(T a) { return a ? (u32)P - a : 0; }
-  static MS_HD T mul(T a, T b) { return (T)(((u64)a * (u64)b) % P); }
+  // Montgomery reduction (R = 2^32): x * 2^-32 mod p for x < p * 2^32;  MU = -p^-1 mod 2^32
+  static constexpr u32 MU = 0x77FFFFFFu;
+  static constexpr u32 R2 = 1172168163u;  // 2^64 mod p
+  static MS_HD T redc(u64 x) {
+    const u32 m = (u32)x * MU;
+    const u32 t = (u32)((x + (u64)m * (u64)P) >> 32);  // x + m*p < 2^63 + 2^63
+    return t >= (u32)P ? t - (u32)P : t;
+  }
+  // canonical in, canonical out: (a*b/R) * R^2 / R  — two 32x32 products + two reductions instead of a 64-bit modulo
+  static MS_HD T mul(T a, T b) { return redc((u64)redc((u64)a * (u64)b) * (u64)R2); }
   static MS_HD T from_u64(u64 v) { return (T)v; }
   static MS_HD u64 to_u64(T v) { return v; }
 };

@@ -17,8 +17,8 @@ def declared_symbols():
 def test_header_symbols_exported():
     syms = declared_symbols()
     assert len(syms) >= 30
-    path = ms.library_path()
-    assert os.path.exists(path), "libministark.so not built: run __graft_entry__.build()"
+    path = ms.build_library()  # hipcc cross-compiles for gfx950 without a GPU (no-op when up to date)
+    assert os.path.exists(path)
     lib = ctypes.CDLL(path)
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
