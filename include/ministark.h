@@ -126,6 +126,13 @@ int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out);
 int ms_merkle_commit(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic,
                      uint8_t* nodes_out, size_t nodes_cap, size_t* nnodes, uint8_t root[32]);
 
+/* MerkleTree::generate_proof(&leaf) (src/merkle.rs:272-288): builds the tree, locates `leaf` (ext limbs) BY VALUE,
+ * first match (merkle.rs:216-225), and writes the serialised MerklePath (layout above) to path_out.
+ * inner_children is 2 (get_parent_idx, merkle.rs:203, is only right for binary trees — DESIGN.md quirk Q14).
+ * *path_len receives the path size; MS_ERR_LEAF_NOT_FOUND if the value is not a leaf. */
+int ms_merkle_prove(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext, size_t lpn, const uint64_t* leaf,
+                    uint8_t* path_out, size_t cap, size_t* path_len);
+
 /* ---- standalone transforms (NTT micro-benchmark + parity tests) ---------- */
 /* `batch` vectors of n elements each, contiguous; natural order in and out. */
 int ms_ntt(ms_ctx* ctx, uint64_t* data, size_t n, size_t batch, int inverse);

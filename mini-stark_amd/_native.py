@@ -251,6 +251,16 @@ class Context:
             return rc, None, None
         return 0, nodes[: nn.value].copy(), bytes(root)
 
+    def merkle_prove(self, leafs, leaf, ext=1, lpn=2):
+        a, p = _u64(leafs)
+        l, lp = _u64(leaf)
+        leaf_num = a.size // ext
+        cap = 64 + lpn * ext * 8 + 64 * 64
+        buf = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = self.L.ms_merkle_prove(self.h, p, C.c_size_t(leaf_num), C.c_int(ext), C.c_size_t(lpn), lp, buf.ctypes.data_as(_u8p), C.c_size_t(cap), C.byref(n))
+        return (rc, None) if rc != 0 else (0, buf[: n.value].tobytes())
+
     def ntt(self, data, inverse=False):
         a = np.array(data, dtype=np.uint64)
         shape = a.shape

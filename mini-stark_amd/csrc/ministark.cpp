@@ -78,6 +78,7 @@ struct CtxBase {
   virtual size_t fri_proof_size() const = 0;
   virtual int fri_proof_read(u8* out) = 0;
   virtual int merkle_commit(const u64* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, u8* nodes_out, size_t cap, size_t* nn, u8* root) = 0;
+  virtual int merkle_prove(const u64* leafs, size_t leaf_num, int ext, size_t lpn, const u64* leaf, u8* out, size_t cap, size_t* len) = 0;
   virtual int ntt(u64* data, size_t n, size_t batch, int inverse) = 0;
   virtual int coset_lde(const u64* coeffs, size_t ncoef, size_t batch, u64 shift, u64* out, size_t L) = 0;
   virtual int bench_lde(size_t blowup, u64 shift) = 0;
@@ -993,6 +994,59 @@ template <class F> struct Ctx : CtxBase {
     dl.release(); dn.release();
     return rc;
   }
+  // src/merkle.rs:272-288 on a standalone binary tree: leaves de-interleaved to SoA limbs, then the same
+  // LeafHash / InnerHash / FindFirst / MerklePath kernels the FRI query phase uses
+  template <int EL>
+  int merkle_prove_t(const u64* leafs, size_t leaf_num, size_t lpn, const u64* leaf, u8* out, size_t cap, size_t* len) {
+    TreeShape ts;
+    RQ(tree_shape(leaf_num, lpn, 2, &ts));
+    if (!canonical(leafs, leaf_num * EL) || !canonical(leaf, EL)) return fail(MS_ERR_ARG, "leaf not canonical");
+    const size_t plen = 8 + lpn * EL * 8 + 8 + (ts.levels - 1) * 2 * 32;
+    if (len) *len = plen;
+    if (!out || cap < plen) return fail(MS_ERR_ARG, "path buffer too small");
+    DevBuf ds, dn, dw;  // SoA leaves | nodes | {target | idx | job tables | path}
+    typedef mspoly::FindJob<F, EL> FJ;
+    typedef msmerkle::PathJob<F, EL> PJ;
+    const size_t off_ix = 256, off_pj = 512, off_path = 1024;
+    int rc = 0;
+    if (ds.ensure(leaf_num * EL * sizeof(T)) || dw.ensure(off_path + plen) || d_io.ensure(leaf_num * EL * 8)) rc = fail(MS_ERR_NOMEM, "merkle_prove");
+    if (!rc) {
+      int e = msrt::h2d(d_io.p, leafs, leaf_num * EL * 8, stream);
+      typename mspoly::TransposeInKernel<F>::Params tp{d_io.as<u64>(), ds.as<T>(), leaf_num, (size_t)EL, leaf_num, F::from_u64(1), 0};
+      if (!e) e = run<mspoly::TransposeInKernel<F>>(K_TRANSPOSE, grid1(leaf_num * EL, mspoly::THREADS), 1, mspoly::THREADS, 0, tp);
+      if (e) rc = fail_rt(e, "leaf upload");
+    }
+    if (!rc) rc = tree_build<EL>(ds.as<T>(), 0, 1, leaf_num, 1, ts, dn);
+    if (!rc) {
+      T tgt[EL]; for (int l = 0; l < EL; l++) tgt[l] = F::from_u64(leaf[l]);
+      unsigned long long none = ~0ULL;
+      u8* base = dw.as<u8>();
+      PJ pj{ds.as<T>(), leaf_num, dn.as<u32>(), leaf_num, (u32)lpn, 2, (u32)(ts.levels - 1), reinterpret_cast<unsigned long long*>(base + off_ix), base + off_path};
+      int e = msrt::h2d(base, tgt, sizeof tgt, stream);
+      if (!e) e = msrt::h2d(base + off_ix, &none, 8, stream);
+      if (!e) e = msrt::h2d(base + off_pj, &pj, sizeof pj, stream);
+      if (!e) e = msrt::sync(stream);  // stack sources
+      typename mspoly::FindFirstKernel<F, EL>::Params fp; fp.jobs = nullptr;
+      fp.inline_job = FJ{ds.as<T>(), leaf_num, leaf_num, reinterpret_cast<const T*>(base), 1, reinterpret_cast<unsigned long long*>(base + off_ix)};
+      if (!e) e = run<mspoly::FindFirstKernel<F, EL>>(K_FIND_FIRST, grid1(leaf_num, mspoly::THREADS), 1, mspoly::THREADS, 0, fp);   // merkle.rs:216-225
+      typename msmerkle::PathKernel<F, EL>::Params pk{reinterpret_cast<const PJ*>(base + off_pj), 1};
+      if (!e) e = run<msmerkle::PathKernel<F, EL>>(K_PATH, 1, 1, 64, 0, pk);                                                          // merkle.rs:230-288
+      if (!e) e = msrt::d2h(pinned, base + off_ix, 8, stream);
+      if (!e) e = msrt::d2h(out, base + off_path, plen, stream);
+      if (!e) e = msrt::sync(stream);
+      if (e) rc = fail_rt(e, "merkle_prove");
+      else if (*reinterpret_cast<unsigned long long*>(pinned) == ~0ULL) rc = fail(MS_ERR_LEAF_NOT_FOUND, "leaf is not included in the tree");
+    }
+    msrt::sync(stream);
+    ds.release(); dn.release(); dw.release();
+    return rc;
+  }
+  int merkle_prove(const u64* leafs, size_t leaf_num, int ext, size_t lpn, const u64* leaf, u8* out, size_t cap, size_t* len) override {
+    if (!leafs || !leaf) return fail(MS_ERR_ARG, "null argument");
+    if (ext == 1) return merkle_prove_t<1>(leafs, leaf_num, lpn, leaf, out, cap, len);
+    if (ext == E) return merkle_prove_t<E>(leafs, leaf_num, lpn, leaf, out, cap, len);
+    return fail(MS_ERR_ARG, "ext must be 1 or the field's extension degree");
+  }
   int ntt(u64* data, size_t n, size_t batch, int inverse) override {
     if (!data || !n || !is_pow2(n)) return fail(MS_ERR_SHAPE, "ntt size must be a power of two");
     if (ctz64(n) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "ntt size exceeds two-adicity");
@@ -1100,6 +1154,9 @@ size_t ms_fri_proof_size(const ms_ctx* ctx) { return ctx ? B(ctx)->fri_proof_siz
 int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out) { CTX_OR_FAIL; return B(ctx)->fri_proof_read(out); }
 int ms_merkle_commit(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, uint8_t* nodes_out, size_t cap, size_t* nn, uint8_t root[32]) {
   CTX_OR_FAIL; return B(ctx)->merkle_commit(leafs, leaf_num, ext, lpn, ic, nodes_out, cap, nn, root);
+}
+int ms_merkle_prove(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext, size_t lpn, const uint64_t* leaf, uint8_t* out, size_t cap, size_t* len) {
+  CTX_OR_FAIL; return B(ctx)->merkle_prove(leafs, leaf_num, ext, lpn, leaf, out, cap, len);
 }
 int ms_ntt(ms_ctx* ctx, uint64_t* data, size_t n, size_t batch, int inverse) { CTX_OR_FAIL; return B(ctx)->ntt(data, n, batch, inverse); }
 int ms_coset_lde(ms_ctx* ctx, const uint64_t* c, size_t ncoef, size_t batch, uint64_t shift, uint64_t* out, size_t L) { CTX_OR_FAIL; return B(ctx)->coset_lde(c, ncoef, batch, shift, out, L); }

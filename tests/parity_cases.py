@@ -218,3 +218,23 @@ def case_general_closure(mk, field, log_n=6):
     assert a.lde_commit(4, 3, 4)[1] == b.lde_commit(4, 3, 4)[1]
     import mini_stark_amd as ms
     assert b.polys_append(np.zeros(N + 1, dtype=np.uint64)) == ms.ERR_SHAPE   # more than N coefficients: starks.rs:118-119 would panic
+
+
+def case_merkle_prove(mk, field, leaf_num=64, ext=1, lpn=2):
+    """MerkleTree::generate_proof by leaf value (merkle.rs:272-288) incl. duplicates (first match wins, quirk Q7)."""
+    import mini_stark_amd as ms
+    ctx = mk(field)
+    leafs = rand_field(field, (leaf_num, ext), seed=leaf_num + ext)
+    leafs[leaf_num // 2] = leafs[3]            # duplicate value: index 3 must be reported
+    flat = leafs.reshape(-1)
+    rc, nodes, root = orc.merkle_build(flat, ext, lpn, 2)
+    assert rc == 0
+    for idx in (0, 3, leaf_num // 2, leaf_num - 1):
+        rc, path = ctx.merkle_prove(flat, leafs[idx], ext, lpn)
+        orc_rc, opath = orc.merkle_prove(flat, leafs[idx], ext, lpn, 2)
+        assert rc == 0 and orc_rc == 0, ctx.last_error()
+        assert path == opath
+        assert orc.merkle_check_proof(root, path, ext, lpn, 2)
+    missing = (leafs[0] + np.uint64(1)) % np.uint64(MODULUS[field])
+    if not (leafs == missing).all(axis=1).any():
+        assert ctx.merkle_prove(flat, missing, ext, lpn)[0] == ms.ERR_LEAF_NOT_FOUND

@@ -125,3 +125,8 @@ def test_prove_randomised_shapes(mk):
         if log_n + blowup.bit_length() - 1 > 14:
             blowup = 2
         pc.case_prove(mk, field, log_n, blowup, nq_fri=rnd.randrange(0, 4), seed=rnd.randrange(1, 1 << 30), read_big=(log_n <= 6), steps=steps)
+
+
+@pytest.mark.parametrize("field,ext,lpn,n", [(0, 1, 2, 64), (0, 1, 4, 64), (0, 2, 2, 32), (1, 4, 2, 16), (1, 1, 8, 4096)])
+def test_merkle_prove_by_value(mk, field, ext, lpn, n):
+    pc.case_merkle_prove(mk, field, n, ext, lpn)

@@ -169,3 +169,8 @@ def test_wide_air_shape(mk, field):
 @pytest.mark.parametrize("field", [0, 1])
 def test_general_closure_path(mk, field):
     pc.case_general_closure(mk, field)
+
+
+@pytest.mark.parametrize("field,ext,lpn,n", [(0, 1, 2, 64), (0, 1, 4, 64), (0, 2, 2, 32), (1, 4, 2, 16), (1, 1, 8, 4096)])
+def test_merkle_prove_by_value(mk, field, ext, lpn, n):
+    pc.case_merkle_prove(mk, field, n, ext, lpn)
