@@ -89,13 +89,9 @@ template <class F, bool INV, int LOG2H2, int J> struct TwMul;
 template <bool INV, int LOG2H2, int J> struct TwMul<GL, INV, LOG2H2, J> {
   static constexpr int EXP = ((INV ? 153 : 39) * (64 >> LOG2H2) * J) % 192;
   static MS_HD u64 diff_mul(u64 a, u64 b, const u64* w_r, int log_r) {
-#ifdef MS_NTT_NO_SHIFT
-    return GL::mul(GL::sub(a, b), w_r[(size_t)J << (log_r - LOG2H2)]);
-#else
     (void)w_r; (void)log_r;
     if constexpr (EXP >= 96) return gl_mul_pow2<EXP - 96>(GL::sub(b, a));  // 2^96 == -1
     else return gl_mul_pow2<EXP>(GL::sub(a, b));
-#endif
   }
 };
 template <bool INV, int LOG2H2, int J> struct TwMul<BB, INV, LOG2H2, J> {
@@ -152,34 +148,12 @@ template <class F, bool INV, int TH> struct PassKernel {
 #endif
 
   static MS_HD int nphases(const Params& p) { return 2 + subround_count((int)p.log_r); }
-  // LDS: tile r*C | w_r table r | store-twiddle table nk*r | small tables
-  static MS_HD int n_klow(int log_Rp, int log_C) { return log_Rp >= log_C ? 1 : (1 << (log_C - log_Rp)); }
-  // the store twiddles of a tile come from LDS tables when the tile spans at most two k_low values
-#ifndef MS_NTT_TAB  // measured neutral on MI355X (r01): off by default, saves LDS
-  static MS_HD bool use_tab(int, int, bool) { return false; }
-#else
-  static MS_HD bool use_tab(int log_Rp, int log_C, bool last) { return !last && n_klow(log_Rp, log_C) <= 2; }
-#endif
-  static MS_HD size_t lds_bytes(int log_r, int log_C, int log_Rp, bool last) {
+  // LDS: tile r*(C+1) (rows padded by one element: bank spreading) | w_r table r
+  static MS_HD size_t lds_bytes(int log_r, int log_C, int, bool) {
     const size_t r = (size_t)1 << log_r, C = (size_t)1 << log_C;
-#ifndef MS_NTT_SWZ
-    size_t el = r * (C + (C > 1 ? 1 : 0)) + r;
-#else
-    size_t el = r * C + r;
-#endif
-    if (use_tab(log_Rp, log_C, last)) el += (size_t)n_klow(log_Rp, log_C) * (r + 64 + 32);
-    return el * sizeof(T);
+    return (r * (C + (C > 1 ? 1 : 0)) + r) * sizeof(T);
   }
-  // swizzled tile index: unpadded rows of C elements; for C == 16 (128-B rows of u64) the 128-B half a row
-  // occupies inside its 256-B pair is flipped by the parity of row bits 1..4
-  static MS_HD int tix(int row, int cidx, int log_C) {
-#ifndef MS_NTT_SWZ  // rows padded by one element (the XOR-swizzled unpadded layout costs 75 more VGPRs: measured 1.6x slower)
-    return row * ((1 << log_C) + (log_C ? 1 : 0)) + cidx;
-#endif
-    if (log_C != TILE_LOG_C) return (row << log_C) + cidx;
-    const int half = (row ^ (row >> 1) ^ (row >> 2) ^ (row >> 3) ^ (row >> 4)) & 1;
-    return ((row >> 1) << (TILE_LOG_C + 1)) | (half << TILE_LOG_C) | cidx;
-  }
+  static MS_HD int tix(int row, int cidx, int log_C) { return row * ((1 << log_C) + (log_C ? 1 : 0)) + cidx; }
 
   template <int B>
   static MS_DEV void subround(const Params& p, int tid, T* tile, const T* w, int s_lo) {
@@ -215,22 +189,12 @@ template <class F, bool INV, int TH> struct PassKernel {
   static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int, unsigned char* lds) {
     const int K = (int)p.log_r, r = 1 << K, C = 1 << p.log_C, lc = (int)p.log_C;
     T* tile = reinterpret_cast<T*>(lds);
-#ifndef MS_NTT_SWZ
     T* w = tile + (size_t)r * (C + (C > 1 ? 1 : 0));
-#else
-    T* w = tile + (size_t)r * C;
-#endif
-    T* tabA = w + r;                                  // [nk][r]   t_k^(Rp * i_new)
-    const int nk = n_klow((int)p.log_Rp, lc);
-    T* tlow = tabA + (size_t)nk * r;                  // [nk][32]  g^j
-    T* thigh = tlow + (size_t)nk * 32;                // [nk][32]  g^(32 j)
-    T* tabB = thigh + (size_t)nk * 32;                // [nk][32]  t_k^(i_done)   (virtual pass only)
     const size_t n = (size_t)1 << p.log_n;
     const size_t col_stride = n >> K;  // n / r : distance between tile rows in the source
     const size_t f0 = (size_t)bx << p.log_C;
     const int S = subround_count(K);
     const bool transposed = (int)p.log_Rp < lc;       // output of each k_low is one contiguous block
-    const bool tab = use_tab((int)p.log_Rp, lc, p.last != 0);
     if (ph == 0) {
       const T* src = p.src + (size_t)by * p.src_bstride;
       if (p.log_r0 == 0) {
@@ -263,19 +227,6 @@ template <class F, bool INV, int TH> struct PassKernel {
         }
       }
       for (int j = tid; j < r; j += TH) w[j] = p.w_r[j];
-      if (tab && tid < nk * 64) {
-        // per k_low: t = w_n^(k_low), g = t^Rp; tlow[j] = g^j, thigh[j] = g^(32 j)  (j < 32)
-        const int kk = tid >> 6, j = tid & 63;
-        const size_t k_low = (f0 >> p.log_Rp) + kk;
-        const T g = tw_global(p, (k_low << p.log_Rp));
-        T base = g;
-        if (j >= 32) { for (int s = 0; s < 5; s++) base = F::mul(base, base); }  // g^32
-        T acc = F::from_u64(1);
-        const int e = j & 31;
-        for (int b = 0; b < 5; b++) { if ((e >> b) & 1) acc = F::mul(acc, base); base = F::mul(base, base); }
-        (j < 32 ? tlow : thigh)[kk * 32 + e] = acc;
-        if (p.log_r0 && j < (1 << p.log_r0)) tabB[kk * 32 + j] = tw_global(p, k_low * (size_t)j);
-      }
       return;
     }
     if (ph <= S) {
@@ -284,12 +235,6 @@ template <class F, bool INV, int TH> struct PassKernel {
       for (int t = 0; t < s; t++) done += subround_bits(K, t);
       const int b = subround_bits(K, s);
       const int s_lo = K - done - b;
-      if (s == 0 && tab) {  // finish the store-twiddle table while the first exchange runs
-        for (int idx = tid; idx < nk * r; idx += TH) {
-          const int kk = idx >> K, i = idx & (r - 1);
-          tabA[idx] = F::mul(tlow[kk * 32 + (i & 31)], thigh[kk * 32 + (i >> 5)]);
-        }
-      }
       switch (b) {
         case 1: subround<1>(p, tid, tile, w, s_lo); break;
         case 2: subround<2>(p, tid, tile, w, s_lo); break;
@@ -315,14 +260,9 @@ template <class F, bool INV, int TH> struct PassKernel {
       }
       T v = tile[tix(row, cidx, lc)];
       const size_t k_low = (f0 + cidx) >> p.log_Rp;
-      if (!p.last && k_low) {
-        if (tab) {
-          v = F::mul(v, tabA[(kk << K) + inew]);
-          if (p.log_r0 && i_done) v = F::mul(v, tabB[kk * 32 + i_done]);
-        } else {  // w_n^(k_low * (output index so far)); the i_done term belongs to the virtual pass
-          const size_t e = k_low * (((size_t)inew << p.log_Rp) + (p.log_r0 ? (size_t)i_done : 0));
-          if (e) v = F::mul(v, tw_global(p, e));
-        }
+      if (!p.last && k_low) {  // w_n^(k_low * (output index so far)); the i_done term belongs to the virtual pass
+        const size_t e = k_low * (((size_t)inew << p.log_Rp) + (p.log_r0 ? (size_t)i_done : 0));
+        if (e) v = F::mul(v, tw_global(p, e));
       }
       if (do_scale) v = F::mul(v, p.scale);
       const size_t out = ((k_low << p.log_Rp) << K) + ((size_t)(f0 + cidx) & (size_t)Rp_m) + ((size_t)inew << p.log_Rp);

@@ -93,13 +93,9 @@ __global__ void __launch_bounds__(K::THREADS, MinWaves<K>::v) ms_kmain(const typ
 template <class K>
 inline int launch(Stream* s, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
   if (threads != K::THREADS) return (int)hipErrorInvalidValue;
-  if (lds_bytes > 65536) {  // opt in to more than 64 KiB of dynamic LDS (once per kernel)
-    static size_t granted = 0;
-    if (lds_bytes > granted) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ms_kmain<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) return (int)e;
-      granted = lds_bytes;
-    }
+  if (lds_bytes > 65536) {  // opt in to more than 64 KiB of dynamic LDS (per device: set on every such launch, microseconds)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ms_kmain<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(ms_kmain<K>), dim3(gx, gy, 1), dim3(threads, 1, 1), lds_bytes, s, p);
   return (int)hipGetLastError();
