@@ -26,10 +26,9 @@ struct GL {
   static constexpr u64 NR2 = 7;
   static constexpr int MAX_DIGITS = 20;
   static MS_HD T add(T a, T b) {
-    T s = a + b;
-    if (s < a) s += EPS;         // wrapped: + 2^64 == + EPS (mod p); result < p
-    else if (s >= P) s -= P;
-    return s;
+    const T s = a + b;
+    const T t = s - P;           // also the wrapped case: s + 2^64 - p == s - p (mod 2^64)
+    return (s < a || s >= P) ? t : s;
   }
   static MS_HD T sub(T a, T b) {
     T d = a - b;

@@ -290,7 +290,7 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
   static_assert(K >= 5 && K <= 9 && (TH == 256 || TH == 512) && R >= RPT, "unsupported tile");
 
   static MS_HD int nphases(const Params&) { return 2 + S; }
-  static MS_HD size_t lds_bytes() { return ((size_t)R * CP + R + NIT) * sizeof(T); }
+  static MS_HD size_t lds_bytes() { return ((size_t)R * CP + 2 * R) * sizeof(T); }
   static MS_HD bool applicable(const Params& p) {
     return p.log_r == K && p.log_C == LC && p.log_r0 == 0 && (p.log_Rp == 0 || p.log_Rp >= LC);
   }
@@ -338,18 +338,18 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
     trow[IT * RPT * CP] = src[(size_t)(IT * RPT) * cs];
     if constexpr (IT + 1 < NIT) load_rows<IT + 1>(src, cs, trow);
   }
-  template <int IT> static MS_DEV void store_rows(const Params& p, const T* trow, T* out, T a, const T* tst, bool tw, bool do_scale) {
+  template <int IT> static MS_DEV void store_rows(const Params& p, const T* trow, T* out, const T* twr, bool tw, bool do_scale) {
     T v = trow[IT * RPT * CP];
-    if (tw) v = F::mul(v, F::mul(a, tst[IT]));
+    if (tw) v = F::mul(v, twr[IT * RPT]);   // one twiddle per tile ROW, shared by its 16 columns
     if (do_scale) v = F::mul(v, p.scale);
     out[(size_t)row_to_inew(IT * RPT, K) << p.log_Rp] = v;
-    if constexpr (IT + 1 < NIT) store_rows<IT + 1>(p, trow, out, a, tst, tw, do_scale);
+    if constexpr (IT + 1 < NIT) store_rows<IT + 1>(p, trow, out, twr, tw, do_scale);
   }
 
   static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int, unsigned char* lds) {
     T* tile = reinterpret_cast<T*>(lds);
     T* w = tile + (size_t)R * CP;
-    T* tst = w + R;                                // [NIT] store twiddles of the sweep offsets
+    T* twr = w + R;                                // [R] store twiddle of every tile row: w_n^(k_low * Rp * i_new(row))
     const size_t n = (size_t)1 << p.log_n, cs = n >> K, f0 = (size_t)bx << LC;
     const int cidx = tid & (C - 1), rb = tid >> LC;
     if (ph == 0) {
@@ -363,9 +363,9 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
         }
       }
       for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
-      if (!p.last && p.log_Rp && tid < NIT) {
+      if (!p.last && p.log_Rp) {
         const size_t k_low = f0 >> p.log_Rp;
-        tst[tid] = tw_global(p, ((size_t)row_to_inew(tid * RPT, K) * k_low) << p.log_Rp);
+        if (k_low) for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row, K) * k_low) << p.log_Rp);
       }
       return;
     }
@@ -382,10 +382,8 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
       const size_t f = f0 + cidx, k_low = f0 >> p.log_Rp, i_done = f & (((size_t)1 << p.log_Rp) - 1);
       const int inew_rb = row_to_inew(rb, K);
       const bool tw = !p.last && k_low != 0;
-      T a = F::from_u64(1);
-      if (tw) a = tw_global(p, ((size_t)inew_rb * k_low) << p.log_Rp);
       T* out = dst + ((k_low << p.log_Rp) << K) + i_done + ((size_t)inew_rb << p.log_Rp);
-      store_rows<0>(p, tile + rb * CP + cidx, out, a, tst, tw, do_scale);
+      store_rows<0>(p, tile + rb * CP + cidx, out, twr + rb, tw, do_scale);
     } else {
       // first pass: out = f*r + i_new, i_new fastest across lanes (transposed)
       for (int idx = tid; idx < R * C; idx += TH) {
