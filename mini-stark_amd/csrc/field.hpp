@@ -38,16 +38,23 @@ struct GL {
   static MS_HD T neg(T a) { return a ? P - a : 0; }
   // 128-bit product folded with 2^64 == 2^32 - 1 and 2^96 == -1 (mod p)
   static MS_HD T reduce128(u64 lo, u64 hi) {
-    u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
+    const u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
     u64 t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= EPS;
-    u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * EPS
-    u64 r = t0 + t1;
-    if (r < t1) r += EPS;
-    if (r >= P) r -= P;
-    return r;
+    t0 -= (lo < hi_hi) ? EPS : 0;          // borrow: - 2^64 == - EPS
+    const u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * EPS
+    const u64 r = t0 + t1;
+    const u64 r2 = r + EPS;                // r - p (mod 2^64): the fix for a carry AND for p <= r < 2^64
+    return (r < t1 || r >= P) ? r2 : r;
   }
-  static MS_HD T mul(T a, T b) { return reduce128(a * b, ms_mulhi64(a, b)); }
+  // 128-bit product as four 32x32+64 multiply-adds (v_mad_u64_u32): a*b and umul64hi separately cost two more multiplies
+  static MS_HD T mul(T a, T b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 p01 = (u64)a0 * b1 + (p00 >> 32);            // < 2^64: (2^32-1)^2 + 2^32 - 1
+    const u64 p10 = (u64)a1 * b0 + (u32)p01;
+    const u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    return reduce128((p10 << 32) | (u32)p00, p11);
+  }
   static MS_HD T from_u64(u64 v) { return v; }
   static MS_HD u64 to_u64(T v) { return v; }
 };
