@@ -106,19 +106,30 @@ template <int RW> struct ShaStream {
   static_assert((RW & (RW - 1)) == 0 && RW >= 32, "ring must be a power of two >= 2 blocks");
   Sha256 h;
   u32* ring; int nthreads, tid;
-  u64 acc;     // the low 8*pend bits are bytes not yet emitted as a whole word
-  u32 pend;    // 0..3
+  u32 acc;     // the low `pbits` bits are bytes not yet emitted as a whole word
+  u32 pbits;   // 8 * pending bytes: 0, 8, 16 or 24
   u32 total;   // bytes appended
   u32 done;    // bytes compressed
-  MS_HD void init(u32* lds_words, int nthreads_, int tid_) { h.init(); ring = lds_words; nthreads = nthreads_; tid = tid_; acc = 0; pend = 0; total = 0; done = 0; }
+  MS_HD void init(u32* lds_words, int nthreads_, int tid_) { h.init(); ring = lds_words; nthreads = nthreads_; tid = tid_; acc = 0; pbits = 0; total = 0; done = 0; }
+  MS_HD void emit(u32 word) { ring[((total >> 2) & (RW - 1)) * nthreads + tid] = word; }
+  // append four bytes (most significant first): the stream word that completes is one funnel shift of (pending, w)
+  MS_HD void append4(u32 w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    emit(__builtin_amdgcn_alignbit(acc, w, pbits));
+#else
+    emit((u32)((((u64)acc << 32) | w) >> pbits));
+#endif
+    acc = w;
+    total += 4;
+  }
   // append the k (1..4) low-order bytes of w, most significant first
   MS_HD void append(u32 w, u32 k) {
-    acc = (acc << (8 * k)) | (u64)(k == 4 ? w : (w & ((1u << (8 * k)) - 1u)));
-    pend += k;
-    if (pend >= 4) {
-      pend -= 4;
-      ring[((total >> 2) & (RW - 1)) * nthreads + tid] = (u32)(acc >> (8 * pend));
-    }
+    const u32 kb = 8 * k;
+    const u64 a64 = ((u64)acc << kb) | (u64)(k == 4 ? w : (w & ((1u << kb) - 1u)));
+    const u32 nb = pbits + kb;
+    if (nb >= 32) { emit((u32)(a64 >> (nb - 32))); pbits = nb - 32; }
+    else pbits = nb;
+    acc = (u32)a64;
     total += k;
   }
   MS_HD void put(u32 ch) { append(ch, 1); }
@@ -137,9 +148,9 @@ template <int RW> struct ShaStream {
     const u64 bits = (u64)total * 8;
     append(0x80, 1);
     while (total & 3) append(0, 1);
-    while ((total & 63) != 56) append(0, 4);
-    append((u32)(bits >> 32), 4);
-    append((u32)bits, 4);
+    while ((total & 63) != 56) append4(0);
+    append4((u32)(bits >> 32));
+    append4((u32)bits);
   }
 };
 
@@ -178,16 +189,17 @@ template <class F, class S> MS_HD void put_dec(S& s, typename F::T v_, int zero_
 #pragma unroll
   for (int j = 0; j < NCH; j++) {
     const int k = 4 * (j + 1) - (int)lead;
-    if (k > 0) s.append(pack4(c[j]), k > 4 ? 4u : (u32)k);
+    if (k >= 4) s.append4(pack4(c[j]));             // every chunk after the leading one
+    else if (k > 0) s.append(pack4(c[j]), (u32)k);  // leading chunk: 1..3 digits
   }
 }
 template <class F, int E> struct Display {
   template <class S> static MS_HD void put(S& s, const typename F::T* c, int zae) {
-    s.append(0x51756164u, 4); s.append(0x45787446u, 4); s.append(0x69656c64u, 4); s.append('(', 1);  // "QuadExtField("
+    s.append4(0x51756164u); s.append4(0x45787446u); s.append4(0x69656c64u); s.append('(', 1);     // "QuadExtField("
     Display<F, E / 2>::put(s, c, zae);
     s.append(0x202b20u, 3);                                                                          // " + "
     Display<F, E / 2>::put(s, c + E / 2, zae);
-    s.append(0x202a2075u, 4); s.append(')', 1);                                                      // " * u)"
+    s.append4(0x202a2075u); s.append(')', 1);                                                        // " * u)"
   }
 };
 template <class F> struct Display<F, 1> {
