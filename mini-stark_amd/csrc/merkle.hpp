@@ -136,9 +136,10 @@ template <int RW> struct ShaStream {
   MS_HD void drain() {
     while (total - done >= 64) {
       u32 w[16];
-      const u32 base = done >> 2;
+      // `done` is a multiple of 64 bytes, so the block starts at a ring word that is a multiple of 16: no per-word wrap
+      const u32* blk = ring + ((done >> 2) & (RW - 1)) * nthreads + tid;
 #pragma unroll
-      for (int i = 0; i < 16; i++) w[i] = ring[((base + i) & (RW - 1)) * nthreads + tid];
+      for (int i = 0; i < 16; i++) w[i] = blk[i * nthreads];
       h.compress(w);
       done += 64;
     }
