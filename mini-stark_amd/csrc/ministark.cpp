@@ -166,7 +166,7 @@ template <class F> struct Ctx : CtxBase {
   std::map<int, Plan*> plans;  // key = (log_n*4 + log_pad)*2 + inverse
   DevBuf ntt_scratch;
   int ntt_kmax = 9;            // largest tile (log2 rows) of a multi-pass plan; MS_NTT_KMAX overrides (tuning)
-  int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1, ntt_fast = 1, ntt_virt_min_single = 1;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
+  int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1, ntt_fast = 1, ntt_fast_min = 22, ntt_fast_max = 24;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
 
   // log_pad: the input is zero beyond n >> log_pad
   int get_plan(int log_n, int log_pad, bool inverse, Plan** out) {
@@ -191,7 +191,7 @@ template <class F> struct Ctx : CtxBase {
       }
       // measured on MI355X (tools/ntt_bench.py, r01): zero-padded transforms of 2^22..2^24 points are fastest as plain 3-pass plans
       // on the compile-time specialised tiles (2^8-row tiles); smaller and larger ones with the virtual-pass plans
-      if (ntt_fast && bestP > 1 && (log_pad == 0 || (log_n >= 22 && log_n <= 24))) {
+      if (ntt_fast && bestP > 1 && (log_pad == 0 || (log_n >= ntt_fast_min && log_n <= ntt_fast_max))) {
         best_rho = 0; log_pad = 0;
         bestP = (log_n + ntt_kmax - 1) / ntt_kmax; if (bestP < 2) bestP = 2;
       }
@@ -425,6 +425,8 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_MAXRHO")) { int v = atoi(e); if (v >= 0 && v <= msntt::MAX_LOG_RHO) ntt_maxrho = v; }
     if (const char* e = getenv("MS_NTT_TH512")) ntt_th512 = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
+    if (const char* e = getenv("MS_NTT_FAST_MIN")) ntt_fast_min = atoi(e);
+    if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
     CK(msrt::set_device(dev));
     CK(msrt::stream_create(&own_stream));
     stream = own_stream;
