@@ -201,15 +201,15 @@ template <class F> struct Ctx : CtxBase {
       for (int i = 0; i < P; i++) pl->K[i] = m / P + (i < m % P ? 1 : 0);
     }
     const int log_r0 = pl->log_r0;
-    T w = f_root_of_unity<F>(log_n);
-    if (inverse) w = f_inv<F>(w);
+    T wn = f_root_of_unity<F>(log_n);
+    if (inverse) wn = f_inv<F>(wn);
     const size_t n = (size_t)1 << log_n;
     pl->n_inv = f_inv<F>(F::from_u64(n % F::P));
     pl->lo_bits = (log_n + 1) / 2;
     const size_t nlo = (size_t)1 << pl->lo_bits, nhi = (size_t)1 << (log_n - pl->lo_bits);
     std::vector<T> lo(nlo), hi(nhi);
     T x = F::from_u64(1);
-    for (size_t j = 0; j < nlo; j++) { lo[j] = x; x = F::mul(x, w); }
+    for (size_t j = 0; j < nlo; j++) { lo[j] = x; x = F::mul(x, wn); }
     T wh = x;  // w^nlo
     x = F::from_u64(1);
     for (size_t j = 0; j < nhi; j++) { hi[j] = x; x = F::mul(x, wh); }
@@ -870,7 +870,7 @@ template <class F> struct Ctx : CtxBase {
     std::vector<std::vector<SHJ>> tables;  // launch order
     std::vector<int> table_mode;
     {
-      std::vector<SHPlan> plans;
+      std::vector<SHPlan> shplans;
       T* scr = d_sh.as<T>();
       for (size_t i = 0; i <= W; i++) {
         Round* pr = rounds[i];
@@ -886,18 +886,18 @@ template <class F> struct Ctx : CtxBase {
           for (int sgn = 0; sgn < 2; sgn++) {
             void* out = nullptr;
             if (i < W) out = blob + rec_off[i * nq + j] + (6 * E + 1) * 8;
-            plans.push_back(sh_plan(pr->poly.template as<T>(), pr->cap, sgn, 2, mm[sgn], X3, out, true, 1, (size_t)sgn * E, 2 * E,
+            shplans.push_back(sh_plan(pr->poly.template as<T>(), pr->cap, sgn, 2, mm[sgn], X3, out, true, 1, (size_t)sgn * E, 2 * E,
                                     d_h0 + ((i * nq + j) * 2 + sgn) * E, scr));
             scr += sh_scratch_elems(mm[sgn]);
           }
         }
       }
       int max_nl = 1;
-      for (auto& pl : plans) if (pl.nl > max_nl) max_nl = pl.nl;
+      for (auto& pl : shplans) if (pl.nl > max_nl) max_nl = pl.nl;
       // group by level count so that every launch is homogeneous: aggregates bottom-up, finals top-down
       for (int nl = 1; nl <= max_nl; nl++) {
-        for (int l = 0; l + 1 < nl; l++) { std::vector<SHJ> t; for (auto& pl : plans) if (pl.nl == nl) t.push_back(pl.agg[l]); if (!t.empty()) { tables.push_back(t); table_mode.push_back(0); } }
-        for (int l = nl - 1; l >= 0; l--) { std::vector<SHJ> t; for (auto& pl : plans) if (pl.nl == nl) t.push_back(pl.fin[l]); if (!t.empty()) { tables.push_back(t); table_mode.push_back(1); } }
+        for (int l = 0; l + 1 < nl; l++) { std::vector<SHJ> t; for (auto& pl : shplans) if (pl.nl == nl) t.push_back(pl.agg[l]); if (!t.empty()) { tables.push_back(t); table_mode.push_back(0); } }
+        for (int l = nl - 1; l >= 0; l--) { std::vector<SHJ> t; for (auto& pl : shplans) if (pl.nl == nl) t.push_back(pl.fin[l]); if (!t.empty()) { tables.push_back(t); table_mode.push_back(1); } }
       }
     }
     // ---- find-first and path jobs
