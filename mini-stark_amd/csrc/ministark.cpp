@@ -95,6 +95,7 @@ template <class F> struct Ctx : CtxBase {
   typedef Ext<F, E> XE;
 
   int device = 0, zae = 1, trace_mont = 0;
+  int lde_linear = 1;  // MS_LDE_LINEAR=0 disables the linear-provenance shortcut of lde_compute (A/B measurements)
   msrt::Stream* own_stream = nullptr;
   msrt::Stream* stream = nullptr;
   void* pinned = nullptr; size_t pinned_cap = 0;
@@ -395,6 +396,8 @@ template <class F> struct Ctx : CtxBase {
   // ------------------------------------------------------------------ session state
   size_t N = 0, w = 0, L = 0, blowup = 0;
   int npolys = 0; size_t polys_cap = 0;
+  struct Lin { std::vector<u64> s; std::vector<int> idx; };   // provenance of polynomial i: a linear combination of earlier ones (empty: none)
+  std::vector<Lin> poly_lin;
   bool have_trace = false, have_polys = false, have_lde = false, have_validity = false;
   DevBuf d_trace, d_polys, d_coef, d_lde, d_trace_nodes, d_lde_nodes, d_io, d_partials, d_small;
   TreeShape trace_ts, lde_ts;
@@ -425,6 +428,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_MAXRHO")) { int v = atoi(e); if (v >= 0 && v <= msntt::MAX_LOG_RHO) ntt_maxrho = v; }
     if (const char* e = getenv("MS_NTT_TH512")) ntt_th512 = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
+    if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MIN")) ntt_fast_min = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
     CK(msrt::set_device(dev));
@@ -504,6 +508,7 @@ template <class F> struct Ctx : CtxBase {
     if (!have_trace) return fail(MS_ERR_STATE, "interpolate before trace_commit");
     RQ(ntt_run(ctz64(N), true, d_polys.as<T>(), N, N, d_polys.as<T>(), N, w));
     npolys = (int)w; have_polys = true; have_lde = have_validity = false;
+    poly_lin.assign(w, Lin());
     return MS_OK;
   }
   int polys_lincomb(const u64* s, const int* idx, int k) override {
@@ -511,16 +516,8 @@ template <class F> struct Ctx : CtxBase {
     if (!s || !idx || k < 1) return fail(MS_ERR_ARG, "bad lincomb arguments");
     for (int t = 0; t < k; t++) if (idx[t] < 0 || idx[t] >= npolys || s[t] >= F::P) return fail(MS_ERR_ARG, "lincomb index/scalar out of range");
     RQ(ensure_polys(npolys + 2));
-    T* dst = d_polys.as<T>() + (size_t)npolys * N;
-    for (int t0 = 0; t0 < k; t0 += mspoly::MAX_TERMS - 1) {
-      typename mspoly::LincombKernel<F>::Params p;
-      p.polys = d_polys.as<T>(); p.stride = N; p.n = N; p.dst = dst;
-      int kk = 0;
-      if (t0 > 0) { p.s[kk] = F::from_u64(1); p.idx[kk] = npolys; kk++; }  // accumulate onto the partial result
-      for (int t = t0; t < k && kk < mspoly::MAX_TERMS; t++, kk++) { p.s[kk] = F::from_u64(s[t]); p.idx[kk] = idx[t]; }
-      p.k = kk;
-      CK(run<mspoly::LincombKernel<F>>(K_LINCOMB, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
-    }
+    RQ(lincomb_into(d_polys.as<T>(), N, N, s, idx, k, npolys, d_polys.as<T>() + (size_t)npolys * N));
+    { Lin l; l.s.assign(s, s + k); l.idx.assign(idx, idx + k); poly_lin.push_back(l); }
     npolys++; have_lde = have_validity = false;
     return MS_OK;
   }
@@ -532,6 +529,7 @@ template <class F> struct Ctx : CtxBase {
     T* dst = d_polys.as<T>() + (size_t)npolys * N;
     CK(msrt::memset_dev(dst, 0, N * sizeof(T), stream));
     if (n) RQ(upload_narrow(coeffs, n, dst));
+    poly_lin.push_back(Lin());
     npolys++; have_lde = have_validity = false;
     return MS_OK;
   }
@@ -542,16 +540,42 @@ template <class F> struct Ctx : CtxBase {
   }
 
   // ------------------------------------------------------------------ starks.rs:80-95
+  // one lincomb launch chain: dst = sum_t s[t] * base[idx[t]] over n elements (columns `stride` apart)
+  int lincomb_into(const T* base, size_t stride, size_t n, const u64* sc, const int* idx, int k, int self_index, T* dst) {
+    for (int t0 = 0; t0 < k; t0 += mspoly::MAX_TERMS - 1) {
+      typename mspoly::LincombKernel<F>::Params p;
+      p.polys = base; p.stride = stride; p.n = n; p.dst = dst;
+      int kk = 0;
+      if (t0 > 0) { p.s[kk] = F::from_u64(1); p.idx[kk] = self_index; kk++; }  // accumulate onto the partial result
+      for (int t = t0; t < k && kk < mspoly::MAX_TERMS; t++, kk++) { p.s[kk] = F::from_u64(sc[t]); p.idx[kk] = idx[t]; }
+      p.k = kk;
+      CK(run<mspoly::LincombKernel<F>>(K_LINCOMB, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    }
+    return 0;
+  }
+  // starks.rs:80-91.  The coset evaluation is linear, so a polynomial that ms_polys_lincomb defined as
+  // sum_t s_t * P_idx[t] has LDE column sum_t s_t * LDE(P_idx[t]): only polynomials without such provenance
+  // (the trace columns, ms_polys_append uploads) go through the NTT.
   int lde_compute(size_t blowup_, u64 shift) {
     const size_t c = (size_t)npolys;
     const size_t L_ = N * blowup_;
     if (d_coef.ensure(c * N * sizeof(T)) || d_lde.ensure(c * L_ * sizeof(T))) return fail(MS_ERR_NOMEM, "lde");
-    typename msntt::ScalePowKernel<F>::Params sp;
-    sp.src = d_polys.as<T>(); sp.dst = d_coef.as<T>(); sp.src_bstride = N; sp.dst_bstride = N; sp.n = N;
-    sp.s = F::from_u64(shift); sp.s_step = f_pow<F>(sp.s, msntt::ScalePowKernel<F>::THREADS);
+    const T sh = F::from_u64(shift), sh_step = f_pow<F>(sh, msntt::ScalePowKernel<F>::THREADS);
     const int per_block = msntt::ScalePowKernel<F>::THREADS * msntt::ScalePowKernel<F>::ITEMS;
-    CK(run<msntt::ScalePowKernel<F>>(K_SCALE_POW, grid1(N, per_block), (unsigned)c, msntt::ScalePowKernel<F>::THREADS, 0, sp));
-    RQ(ntt_run(ctz64(L_), false, d_coef.as<T>(), N, N, d_lde.as<T>(), L_, c));
+    for (size_t i = 0; i < c;) {  // maximal runs of polynomials that need a transform
+      if (lde_linear && !poly_lin[i].idx.empty()) { i++; continue; }
+      size_t j = i;
+      while (j < c && !(lde_linear && !poly_lin[j].idx.empty())) j++;
+      typename msntt::ScalePowKernel<F>::Params sp;
+      sp.src = d_polys.as<T>() + i * N; sp.dst = d_coef.as<T>() + i * N; sp.src_bstride = N; sp.dst_bstride = N; sp.n = N; sp.s = sh; sp.s_step = sh_step;
+      CK(run<msntt::ScalePowKernel<F>>(K_SCALE_POW, grid1(N, per_block), (unsigned)(j - i), msntt::ScalePowKernel<F>::THREADS, 0, sp));
+      RQ(ntt_run(ctz64(L_), false, d_coef.as<T>() + i * N, N, N, d_lde.as<T>() + i * L_, L_, j - i));
+      i = j;
+    }
+    if (lde_linear)
+      for (size_t i = 0; i < c; i++)
+        if (!poly_lin[i].idx.empty())
+          RQ(lincomb_into(d_lde.as<T>(), L_, L_, poly_lin[i].s.data(), poly_lin[i].idx.data(), (int)poly_lin[i].idx.size(), (int)i, d_lde.as<T>() + i * L_));
     return 0;
   }
   int lde_commit(size_t blowup_, u64 shift, size_t lpn, u8* root) override {

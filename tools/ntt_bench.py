@@ -16,9 +16,11 @@ ap.add_argument("--field", type=int, default=0)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--tag", default="")
+ap.add_argument("--linear", type=int, default=0, help="1: let the LDE stage use the linear-provenance shortcut (3 NTTs + 3 lincombs); 0: six NTTs (kernel measurement)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev)
+os.environ["MS_LDE_LINEAR"] = str(a.linear)
 for lr in a.log_rows:
     ctx = ms.Context(a.field, lib_path=a.lib)
     ctx.set_stream(stream.cuda_stream)
@@ -40,6 +42,6 @@ for lr in a.log_rows:
     N, L, c = 1 << lr, (1 << lr) * a.blowup, 6
     s = 8 if a.field == 0 else 4
     alg = c * (N + L) * s
-    print(json.dumps({"tag": a.tag, "log_rows": lr, "blowup": a.blowup, "field": a.field, "lde_ms": round(ms_per, 4), "alg_GBps": round(alg / ms_per / 1e6, 1),
+    print(json.dumps({"tag": a.tag, "linear_shortcut": a.linear, "log_rows": lr, "blowup": a.blowup, "field": a.field, "lde_ms": round(ms_per, 4), "alg_GBps": round(alg / ms_per / 1e6, 1),
                       "frac_of_8TBps": round(alg / ms_per / 1e6 / 8000, 4)}))
     ctx.close()
