@@ -157,6 +157,17 @@ def main():
             out["cpu_baseline"] = {"value": 1.0 / (ct * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
                                    "sample": f"one 2^{cl}-row proof of the same AIR on the oracle (oracle/ministark_oracle.cpp, 1 thread) took {ct:.2f} s; "
                                              f"scaled linearly x{int(scale)} to 2^{args.log_rows} rows (optimistic for the CPU: ignores the log factor)"}
+            # the same sample with OpenMP over the oracle's independent loops (columns, leaf groups, tree levels):
+            # what a rayon-enabled reference could reach on this host; the reference itself is single-threaded (README.md:33)
+            nthr = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0))))
+            if nthr > 1:
+                orc.set_threads(nthr)
+                c0 = time.perf_counter()
+                pc.drive(orc.Session(args.field), args.field, tr, args.blowup, max(0, cfg.fri_queries - 2), seed=1, q_ood=cfg.constrain_queries, read_big=False)
+                ctm = time.perf_counter() - c0
+                orc.set_threads(1)
+                out["cpu_baseline"]["all_cores"] = {"value": 1.0 / (ctm * scale), "unit": "proofs/s", "cores": nthr, "kind": "port",
+                                                    "sample": f"same 2^{cl}-row proof with OpenMP x{nthr} took {ctm:.2f} s"}
         print(json.dumps(out), flush=True)
     grp.close()
 

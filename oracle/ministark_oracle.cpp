@@ -32,6 +32,14 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+// Threads for the embarrassingly parallel loops (leaf groups, tree levels, columns, limbs).  Default 1: the
+// reference is single-threaded (README.md:33 lists rayon as not done).  or_set_threads(n) is used only by the
+// bench's "all cores" CPU baseline.
+static int g_threads = 1;
 
 typedef uint64_t u64;
 typedef uint32_t u32;
@@ -299,12 +307,15 @@ struct MerkleTree {
     }
     // merkle.rs:116-118 geometric series
     size_t total = 0; { size_t m = node_num; for (;;) { total += m; if (m == 1) break; m /= ic; } }
-    nodes.clear(); nodes.reserve(total);
-    for (size_t g = 0; g < node_num; g++) nodes.push_back(from_leafs(inputs + g * lpn * E, lpn));  // merkle.rs:124-128
-    size_t idx = 0;
-    while (nodes.size() < total) {  // merkle.rs:131-140 (idx advances by inner_children)
-      nodes.push_back(from_nodes(&nodes[idx], ic));
-      idx += ic;
+    nodes.clear();
+    nodes.resize(total);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (size_t g = 0; g < node_num; g++) nodes[g] = from_leafs(inputs + g * lpn * E, lpn);  // merkle.rs:124-128
+    // merkle.rs:131-140 (each parent hashes inner_children consecutive earlier nodes), level by level
+    for (size_t child0 = 0, m = node_num; m > 1; child0 += m, m /= ic) {
+      const size_t parent0 = child0 + m;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+      for (size_t j = 0; j < m / ic; j++) nodes[parent0 + j] = from_nodes(&nodes[child0 + j * ic], ic);
     }
     leafs.assign(inputs, inputs + leaf_num * E);
     return OR_OK;
@@ -458,6 +469,7 @@ template <class F, int E> static std::vector<u64> ext_evaluate_over_domain(const
   std::vector<u64> ev(D * E, 0);
   for (size_t i = 0; i < p.size() && i < D; i++) for (int k = 0; k < E; k++) ev[i * E + k] = p[i].c[k];
   NttPlan<F> pl(D, false);
+#pragma omp parallel for num_threads(g_threads)
   for (int k = 0; k < E; k++) ntt_inplace<F>(pl, ev.data() + k, E);
   return ev;
 }
@@ -545,6 +557,7 @@ template <class F, int E> struct Session : SessionBase {
     polys.assign(w, std::vector<u64>(N));
     NttPlan<F> pl(N, true);
     u64 ninv = f_inv<F>(N % F::P);
+#pragma omp parallel for num_threads(g_threads)
     for (size_t c = 0; c < w; c++) {
       for (size_t j = 0; j < N; j++) polys[c][j] = trace[j * w + c];  // air.rs:151-153
       ntt_inplace<F>(pl, polys[c].data(), 1);                         // air.rs:154
@@ -579,8 +592,9 @@ template <class F, int E> struct Session : SessionBase {
     size_t c = polys.size();
     lde.assign(L * c, 0);
     NttPlan<F> pl(L, false);
-    std::vector<u64> col(L);
+#pragma omp parallel for num_threads(g_threads)
     for (size_t i = 0; i < c; i++) {
+      std::vector<u64> col(L);
       u64 s = 1;
       for (size_t k = 0; k < L; k++) {  // coset fft: coeff_k * shift^k, zero padded
         col[k] = k < N ? F::mul(polys[i][k], s) : 0;
@@ -857,6 +871,14 @@ static int fri_verify(int zae, size_t rounds, size_t nq, const u64* betas_in, co
 
 extern "C" {
 
+void or_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int or_max_threads() {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 int or_is_power_of_two(u64 n) { return is_power_of_two(n); }
 long or_logarithm_of_two_k(u64 n, u64 base) { return logarithm_of_two_k(n, base); }
 u64 or_ceil_log2_k(u64 n, u64 base) { return ceil_log2_k(n, base); }

@@ -56,6 +56,15 @@ def _u64(a):
     return a, a.ctypes.data_as(u64p)
 
 
+def set_threads(n):
+    """OpenMP threads for the oracle's independent loops (default 1, like the reference)."""
+    lib().or_set_threads(C.c_int(n))
+
+
+def max_threads():
+    return int(lib().or_max_threads())
+
+
 def modulus(field):
     return int(lib().or_modulus(C.c_int(field)))
 
