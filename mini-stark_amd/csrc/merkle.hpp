@@ -58,6 +58,35 @@ MS_HD u32 xor3(u32 a, u32 b, u32 c) {
 #endif
 }
 
+constexpr u32 SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+// K[i] + W[i] of the FIPS 180-4 padding block that follows a message of MSG_BITS bits ending on a block
+// boundary (0x80, zeros, bit length).  Evaluated by the compiler: the bitop3 builtins of the run-time path
+// are opaque to constant propagation, so the fold is spelled out here instead of being left to the optimiser.
+struct PadBlockKW { u32 kw[64]; };
+constexpr u32 c_rotr(u32 x, int n) { return (x >> n) | (x << (32 - n)); }
+constexpr PadBlockKW make_pad_block_kw(u32 msg_bits) {
+  PadBlockKW r{};
+  u32 w[64] = {};
+  w[0] = 0x80000000u; w[15] = msg_bits;
+  for (int i = 16; i < 64; i++) {
+    const u32 s0 = c_rotr(w[i - 15], 7) ^ c_rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+    const u32 s1 = c_rotr(w[i - 2], 17) ^ c_rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+    w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+  }
+  for (int i = 0; i < 64; i++) r.kw[i] = SHA_K[i] + w[i];
+  return r;
+}
+template <u32 MSG_BITS> struct PadBlock { static constexpr PadBlockKW T = make_pad_block_kw(MSG_BITS); };
+
 struct Sha256 {
   u32 st[8];
   MS_HD void init() {
@@ -66,15 +95,6 @@ struct Sha256 {
   }
   // one compression of the 16 big-endian words w[0..15] (clobbers w)
   MS_HD void compress(u32 (&w)[16]) {
-    constexpr u32 K[64] = {
-        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
-        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
-        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
-        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
-        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
-        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
-        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
-        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
     u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
 #pragma unroll
     for (int i = 0; i < 64; i++) {
@@ -86,7 +106,22 @@ struct Sha256 {
       }
       u32 S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
       u32 ch = ch3(e, f, g);
-      u32 t1 = h + S1 + ch + K[i] + w[i & 15];
+      u32 t1 = h + S1 + ch + SHA_K[i] + w[i & 15];
+      u32 S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+      u32 mj = maj3(a, b, c);
+      u32 t2 = S0 + mj;
+      h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+  }
+  // the padding block after MSG_BITS message bits: no message schedule at run time, K+W is one literal per round
+  template <u32 MSG_BITS> MS_HD void compress_pad_block() {
+    u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      u32 S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+      u32 ch = ch3(e, f, g);
+      u32 t1 = h + S1 + ch + PadBlock<MSG_BITS>::T.kw[i];
       u32 S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
       u32 mj = maj3(a, b, c);
       u32 t2 = S0 + mj;
@@ -96,90 +131,151 @@ struct Sha256 {
   }
 };
 
-// byte stream -> SHA-256.  The message bytes are packed into big-endian words in a
-// per-thread ring of RW words that lives in LDS word-interleaved across the
-// workgroup (word i of thread t at ring[i*nthreads + t]: conflict free).
-// `put` never compresses; the owner calls `drain` after each element, so the
-// 64-round compression is instantiated exactly ONCE in the kernel (inlining it
-// at every put() site made the kernel I-cache bound).
-template <int RW> struct ShaStream {
-  static_assert((RW & (RW - 1)) == 0 && RW >= 32, "ring must be a power of two >= 2 blocks");
-  Sha256 h;
-  u32* ring; int nthreads, tid;
-  u32 acc;     // the low `pbits` bits are bytes not yet emitted as a whole word
-  u32 pbits;   // 8 * pending bytes: 0, 8, 16 or 24
-  u32 total;   // bytes appended
-  u32 done;    // bytes compressed
-  MS_HD void init(u32* lds_words, int nthreads_, int tid_) { h.init(); ring = lds_words; nthreads = nthreads_; tid = tid_; acc = 0; pbits = 0; total = 0; done = 0; }
-  MS_HD void emit(u32 word) { ring[((total >> 2) & (RW - 1)) * nthreads + tid] = word; }
-  // append four bytes (most significant first): the stream word that completes is one funnel shift of (pending, w)
-  MS_HD void append4(u32 w) {
+// {hi, lo} >> sh (low word), sh in {0, 8, 16, 24}
+MS_HD u32 funnel_r(u32 hi, u32 lo, u32 sh) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    emit(__builtin_amdgcn_alignbit(acc, w, pbits));
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
 #else
-    emit((u32)((((u64)acc << 32) | w) >> pbits));
+  return sh ? ((hi << (32 - sh)) | (lo >> sh)) : lo;
 #endif
-    acc = w;
-    total += 4;
-  }
-  // append the k (1..4) low-order bytes of w, most significant first
-  MS_HD void append(u32 w, u32 k) {
-    const u32 kb = 8 * k;
-    const u64 a64 = ((u64)acc << kb) | (u64)(k == 4 ? w : (w & ((1u << kb) - 1u)));
-    const u32 nb = pbits + kb;
-    if (nb >= 32) { emit((u32)(a64 >> (nb - 32))); pbits = nb - 32; }
-    else pbits = nb;
-    acc = (u32)a64;
-    total += k;
-  }
-  MS_HD void put(u32 ch) { append(ch, 1); }
-  MS_HD void drain() {
-    while (total - done >= 64) {
-      u32 w[16];
-      // `done` is a multiple of 64 bytes, so the block starts at a ring word that is a multiple of 16: no per-word wrap
-      const u32* blk = ring + ((done >> 2) & (RW - 1)) * nthreads + tid;
+}
+// ({hi, lo} << 8*l) >> 32, l in 0..3: the four bytes of the pair that start l bytes into `hi`.
+// `sel` = drop_sel(l) is loop invariant (v_perm_b32 byte selector).
+MS_HD u32 drop_sel(u32 l) { return 0x07060504u - l * 0x01010101u; }
+MS_HD u32 drop_bytes(u32 hi, u32 lo, u32 l, u32 sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)l;
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  (void)sel;
+  return l ? ((hi << (8 * l)) | (lo >> (32 - 8 * l))) : hi;
+#endif
+}
+
+// byte stream -> SHA-256.  The not-yet-compressed tail of the message (< 64 bytes between appends) lives as
+// big-endian words in a per-thread buffer of NWORDS words in LDS, word-interleaved across the workgroup
+// (word i of thread t at buf[i*NT + t]: conflict free); buf[0] is always the first word of the next block.
+// Appends are whole-register operations: a string of NW packed words is shifted into place by one funnel
+// shift per word and stored at compile-time offsets from the write pointer; the word that holds the
+// stream's tail is always stored with zero fill, so LDS is a valid image of the pending bytes at any time.
+// `drain` is the only compression site (the 64-round compression is instantiated ONCE per kernel: inlining
+// it at every append made the kernel I-cache bound); after a block is compressed the leftover words move
+// down to the buffer start.  Between two drains at most 4*(NWORDS-17)-3 bytes may be appended.
+template <int NWORDS, int NT> struct ShaStream {
+  static_assert(NWORDS > 17 && NWORDS <= 32, "buffer = one block + slack");
+  Sha256 h;
+  u32* buf;    // this thread's word 0
+  u32 acc;     // the last four bytes appended (low byte = most recent)
+  u32 total;   // bytes appended
+  u32 done;    // words compressed (multiple of 16) = stream index of buf[0]
+  MS_HD void init(u32* lds_words, int tid_) { h.init(); buf = lds_words + tid_; acc = 0; total = 0; done = 0; }
+  // append the first nbytes (1 <= nbytes <= 4*NW) bytes of W (big-endian, zero beyond nbytes);
+  // last4 = the last four bytes of the stream after the append (only its low min(4, bytes so far) bytes matter)
+  template <int NW> MS_HD void append_words(const u32 (&W)[NW], u32 nbytes, u32 last4) {
+    const u32 sh = 8u * (total & 3u);
+    u32* wp = buf + ((total >> 2) - done) * NT;
+    u32 prev = acc;
 #pragma unroll
-      for (int i = 0; i < 16; i++) w[i] = blk[i * nthreads];
-      h.compress(w);
-      done += 64;
-    }
+    for (int k = 0; k < NW; k++) { wp[k * NT] = funnel_r(prev, W[k], sh); prev = W[k]; }
+    wp[NW * NT] = funnel_r(prev, 0u, sh);
+    total += nbytes;
+    acc = last4;
   }
-  // FIPS 180-4 padding; caller drains afterwards
-  MS_HD void pad() {
-    const u64 bits = (u64)total * 8;
-    append(0x80, 1);
-    while (total & 3) append(0, 1);
-    while ((total & 63) != 56) append4(0);
-    append4((u32)(bits >> 32));
-    append4((u32)bits);
+  // 1..4 bytes, left-aligned in w (zero below)
+  MS_HD void append_small(u32 w, u32 nbytes) {
+    const u32 W[1] = {w};
+    const u32 l4 = nbytes >= 4 ? w : ((acc << (8 * nbytes)) | (w >> (32 - 8 * nbytes)));
+    append_words<1>(W, nbytes, l4);
+  }
+  // compress every complete block.  With `final` (uniform over the workgroup; the caller has appended the 0x80
+  // byte of a msg_bytes-byte message) the FIPS 180-4 padding is applied on the fly: words past the 0x80 byte
+  // read as zero and the last block carries the bit length.  A second padding block has no message bytes, so
+  // every block is read from buf[0..16).
+  MS_HD void drain(bool final, u32 msg_bytes) {
+    u32 limit = total >> 2, valid_end = 0;
+    if (final) { valid_end = (total + 3) >> 2; limit = ((msg_bytes + 9 + 63) >> 6) << 4; }
+    const u32 done0 = done;
+    while (limit - done >= 16) {
+      u32 w[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) w[i] = buf[i * NT];
+      if (final) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = (done + i < valid_end) ? w[i] : 0u;
+        if (limit - done == 16) { w[14] = 0; w[15] = msg_bytes * 8u; }  // messages are far below 2^29 bytes
+      }
+      h.compress(w);
+      done += 16;
+    }
+    if (!final && done != done0) {  // one block went (appends between drains are < 64 bytes): move the leftover down
+      u32 t[NWORDS - 16];
+#pragma unroll
+      for (int k = 0; k < NWORDS - 16; k++) t[k] = buf[(k + 16) * NT];
+#pragma unroll
+      for (int k = 0; k < NWORDS - 16; k++) buf[k * NT] = t[k];
+    }
   }
 };
 
-// four decimal digits of c < 10^4 as big-endian ASCII
-MS_HD u32 pack4(u32 c) {
-  const u32 q = (c * 5243u) >> 19, r = c - q * 100u;      // c / 100, c % 100
-  const u32 d3 = (q * 205u) >> 11, d2 = q - d3 * 10u;      // q / 10, q % 10   (q < 100)
-  const u32 d1 = (r * 205u) >> 11, d0 = r - d1 * 10u;
-  return 0x30303030u + (d3 << 24) + (d2 << 16) + (d1 << 8) + d0;
+// four decimal digits of c < 10^4 as big-endian BCD bytes (add 0x30303030 for ASCII)
+MS_HD u32 bcd4(u32 c) {
+  const u32 q = (c * 5243u) >> 19;                     // c / 100
+  const u32 t = c + q * 65436u;                         // (q << 16) | (c % 100)
+  const u32 tens = ((t * 103u) >> 10) & 0x000F000Fu;    // q / 10, (c % 100) / 10
+  const u32 ones = t - tens * 10u;
+  return (tens << 8) + ones;
 }
+MS_HD u32 pack4(u32 c) { return bcd4(c) + 0x30303030u; }
+MS_HD u32 clz32(u32 x) { return (u32)__builtin_clz(x); }
+
+// v -> NCH chunks of four decimal digits, most significant first
+MS_HD void dec_chunks(const GL&, u64 v, u32 (&c)[5]) {
+  // q1 = v / 10^16 from the high word: floor(vh * floor(2^84 / 10^16) / 2^52) is q1 or q1 - 1
+  const u32 vh = (u32)(v >> 32);
+  u32 q1 = (u32)(((u64)vh * 1934281311u) >> 32) >> 20;
+  u64 r = v - (u64)q1 * 10000000000000000ULL;
+  if (r >= 10000000000000000ULL) { r -= 10000000000000000ULL; q1++; }
+  // q2 = r / 10^8 (r < 10^16 < 2^54) from r >> 22: floor(x * floor(2^54 / 10^8) / 2^32) is q2 or q2 - 1
+  const u32 x = (u32)(r >> 22);
+  u32 q2 = (u32)(((u64)x * 180143985u) >> 32);
+  u32 r2 = (u32)r - q2 * 100000000u;  // < 2 * 10^8: the low word is enough
+  if (r2 >= 100000000u) { r2 -= 100000000u; q2++; }
+  c[0] = q1;
+  c[1] = q2 / 10000u; c[2] = q2 - c[1] * 10000u;
+  c[3] = r2 / 10000u; c[4] = r2 - c[3] * 10000u;
+}
+MS_HD void dec_chunks(const BB&, u64 v, u32 (&c)[3]) {
+  const u32 x = (u32)v;
+  c[0] = x / 100000000u; const u32 r = x - c[0] * 100000000u;
+  c[1] = r / 10000u; c[2] = r - c[1] * 10000u;
+}
+
 // canonical decimal of a base element, most significant digit first, no leading zeros;
-// ZERO -> "" (zero_as_empty) or "0".  The value is split into 4-digit chunks that are appended as packed
-// words, skipping the leading zero characters of the zero-padded string.
+// ZERO -> "" (zero_as_empty) or "0".
 template <class F, class S> MS_HD void put_dec(S& s, typename F::T v_, int zero_as_empty) {
   const u64 v = F::to_u64(v_);
-  if (v == 0) { if (!zero_as_empty) s.append('0', 1); return; }
   constexpr int NCH = (F::MAX_DIGITS + 3) / 4;  // 5 (Goldilocks, 20 digits) / 3 (BabyBear, 10 digits -> 12 chars)
   u32 c[NCH];
-  if (NCH == 5) {
-    const u64 hi = v / 100000000ULL; const u32 lo = (u32)(v - hi * 100000000ULL);       // hi < 1.85e11
-    const u32 hi2 = (u32)(hi / 100000000ULL); const u32 mid = (u32)(hi - (u64)hi2 * 100000000ULL);
-    c[0] = hi2; c[1] = mid / 10000u; c[2] = mid - c[1] * 10000u;
-    c[NCH - 2] = lo / 10000u; c[NCH - 1] = lo - c[NCH - 2] * 10000u;
-  } else {
-    const u32 x = (u32)v;
-    c[0] = x / 100000000u; const u32 r = x - c[0] * 100000000u;
-    c[1] = r / 10000u; c[NCH - 1] = r - c[1] * 10000u;
+  dec_chunks(F(), v, c);
+  if (c[0] != 0) {
+    // common case (>= 10^16 resp. >= 10^8): at most 3 leading zero characters, all in the first word.
+    // The 4*NCH characters are packed, shifted left by `lead` bytes and appended as one string.
+    u32 W[NCH];
+    const u32 b0 = bcd4(c[0]);
+    const u32 lead = clz32(b0) >> 3;
+    W[0] = b0 + 0x30303030u;
+#pragma unroll
+    for (int j = 1; j < NCH; j++) W[j] = pack4(c[j]);
+    const u32 sel = drop_sel(lead);
+    u32 X[NCH];
+#pragma unroll
+    for (int j = 0; j + 1 < NCH; j++) X[j] = drop_bytes(W[j], W[j + 1], lead, sel);
+    X[NCH - 1] = drop_bytes(W[NCH - 1], 0u, lead, sel);
+    s.template append_words<NCH>(X, 4u * NCH - lead, W[NCH - 1]);
+    return;
   }
+  if (v == 0) { if (!zero_as_empty) s.append_small(0x30000000u, 1); return; }
+  // short values: chunk by chunk
   u32 lead = 0; bool found = false;  // leading zero characters
 #pragma unroll
   for (int j = 0; j < NCH; j++) {
@@ -187,30 +283,53 @@ template <class F, class S> MS_HD void put_dec(S& s, typename F::T v_, int zero_
     if (!found) lead += z;
     found = found || (c[j] != 0);
   }
-#pragma unroll
-  for (int j = 0; j < NCH; j++) {
+  for (int j = 1; j < NCH; j++) {  // c[0] == 0 here
     const int k = 4 * (j + 1) - (int)lead;
-    if (k >= 4) s.append4(pack4(c[j]));             // every chunk after the leading one
-    else if (k > 0) s.append(pack4(c[j]), (u32)k);  // leading chunk: 1..3 digits
+    if (k >= 4) s.append_small(pack4(c[j]), 4);
+    else if (k > 0) s.append_small(pack4(c[j]) << (8 * (4 - k)), (u32)k);  // leading chunk: 1..3 digits
   }
 }
-template <class F, int E> struct Display {
-  template <class S> static MS_HD void put(S& s, const typename F::T* c, int zae) {
-    s.append4(0x51756164u); s.append4(0x45787446u); s.append4(0x69656c64u); s.append('(', 1);     // "QuadExtField("
-    Display<F, E / 2>::put(s, c, zae);
-    s.append(0x202b20u, 3);                                                                          // " + "
-    Display<F, E / 2>::put(s, c + E / 2, zae);
-    s.append4(0x202a2075u); s.append(')', 1);                                                        // " * u)"
-  }
+// arkworks' Display of an extension element, cut at its base limbs: the characters before and after the
+// decimal of limb k (0 <= k < E).  E = 2: "QuadExtField(" c0 " + " c1 " * u)"; E = 4 nests the same form.
+template <int E> struct Affix;
+template <> struct Affix<1> {
+  static constexpr int MAX_BYTES = 0;
+  template <class S> static MS_HD void before(S&, u32) {}
+  template <class S> static MS_HD void after(S&, u32) {}
 };
-template <class F> struct Display<F, 1> {
-  template <class S> static MS_HD void put(S& s, const typename F::T* c, int zae) { put_dec<F>(s, c[0], zae); }
+template <class S> MS_HD void put_open(S& s) { const u32 W[4] = {0x51756164u, 0x45787446u, 0x69656c64u, 0x28000000u}; s.template append_words<4>(W, 13, 0x656c6428u); }  // "QuadExtField("
+template <class S> MS_HD void put_plus(S& s) { s.append_small(0x202b2000u, 3); }                                                                                  // " + "
+template <class S> MS_HD void put_close(S& s) { const u32 W[2] = {0x202a2075u, 0x29000000u}; s.template append_words<2>(W, 5, 0x2a207529u); }                     // " * u)"
+template <> struct Affix<2> {
+  static constexpr int MAX_BYTES = 13;  // per limb, before + after
+  template <class S> static MS_HD void before(S& s, u32 k) { if (k == 0) put_open(s); else put_plus(s); }
+  template <class S> static MS_HD void after(S& s, u32 k) { if (k == 1) put_close(s); }
+};
+template <> struct Affix<4> {
+  static constexpr int MAX_BYTES = 26;
+  template <class S> static MS_HD void before(S& s, u32 k) {
+    if (k == 0) {  // "QuadExtField(QuadExtField("
+      const u32 W[7] = {0x51756164u, 0x45787446u, 0x69656c64u, 0x28517561u, 0x64457874u, 0x4669656cu, 0x64280000u};
+      s.template append_words<7>(W, 26, 0x656c6428u);
+    } else if (k == 2) {  // " + QuadExtField("
+      const u32 W[4] = {0x202b2051u, 0x75616445u, 0x78744669u, 0x656c6428u};
+      s.template append_words<4>(W, 16, 0x656c6428u);
+    } else put_plus(s);
+  }
+  template <class S> static MS_HD void after(S& s, u32 k) {
+    if (k == 1) put_close(s);
+    else if (k == 3) {  // " * u) * u)"
+      const u32 W[3] = {0x202a2075u, 0x29202a20u, 0x75290000u};
+      s.template append_words<3>(W, 10, 0x2a207529u);
+    }
+  }
 };
 
 // Leaf-group hashing.  Element f of the committed vector lives at
 //   base + (f % width) * col_stride + (f / width) * row_stride + limb * limb_stride
 // (row-major trace: width=1,row_stride=1; column-major LDE: width=c,col_stride=L;
 //  FRI codeword: width=1, limb_stride=D).
+// One thread owns one digest and walks the base limbs of its group: affix, decimal, affix, drain.
 template <class F, int E> struct LeafHashKernel {
   typedef typename F::T T;
   static constexpr int THREADS = msmerkle::THREADS;
@@ -220,29 +339,32 @@ template <class F, int E> struct LeafHashKernel {
     size_t ngroups;
     u32* nodes;  // 8 words per digest, standard byte order in memory
   };
-  // ring words: 63 leftover bytes + the longest element string must fit
-  static constexpr int ELEM_MAX = (E == 1) ? F::MAX_DIGITS : (E == 2 ? 21 + 2 * F::MAX_DIGITS : 63 + 4 * F::MAX_DIGITS);
-  static constexpr int RW = (63 + ELEM_MAX + 3) / 4 <= 32 ? 32 : 64;
+  static constexpr int MAX_BYTES = F::MAX_DIGITS + Affix<E>::MAX_BYTES;  // appended between two drains
+  static constexpr int NWORDS = 16 + (3 + MAX_BYTES + 3) / 4 + 2;
+  typedef ShaStream<NWORDS, THREADS> Stream;
   static MS_HD int nphases(const Params&) { return 1; }
-  static MS_HD size_t lds_bytes() { return (size_t)RW * THREADS * sizeof(u32); }
+  static MS_HD size_t lds_bytes() { return (size_t)NWORDS * THREADS * sizeof(u32); }
   static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char* lds) {
     const size_t g = (size_t)bx * nthreads + tid;
     if (g >= p.ngroups) return;
-    ShaStream<RW> s; s.init(reinterpret_cast<u32*>(lds), nthreads, tid);
+    Stream s; s.init(reinterpret_cast<u32*>(lds), tid);
     size_t f = g * p.lpn;
     size_t row = f / p.width; u32 col = (u32)(f - row * p.width);
-    for (u32 i = 0; i <= p.lpn; i++) {
-      if (i < p.lpn) {
-        T c[E];
-        const T* ptr = p.base + (size_t)col * p.col_stride + row * p.row_stride;
-#pragma unroll
-        for (int k = 0; k < E; k++) c[k] = ptr[(size_t)k * p.limb_stride];
-        Display<F, E>::put(s, c, p.zero_as_empty);
-        if (++col == p.width) { col = 0; row++; }
+    const u32 nlimbs = p.lpn * (u32)E;
+    u32 msg_bytes = 0;
+    for (u32 j = 0; j <= nlimbs; j++) {
+      if (j < nlimbs) {
+        const u32 k = j & (u32)(E - 1);
+        const T v = p.base[(size_t)col * p.col_stride + row * p.row_stride + (size_t)k * p.limb_stride];
+        Affix<E>::before(s, k);
+        put_dec<F>(s, v, p.zero_as_empty);
+        Affix<E>::after(s, k);
+        if (k == (u32)(E - 1) && ++col == p.width) { col = 0; row++; }
       } else {
-        s.pad();
+        msg_bytes = s.total;
+        s.append_small(0x80000000u, 1);
       }
-      s.drain();  // the only compression site
+      s.drain(j == nlimbs, msg_bytes);  // the only compression site
     }
     uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + g * 8);
     uint4_t o0, o1;
@@ -282,12 +404,15 @@ template <int IC> struct InnerHashKernelT {
         h.compress(w);
       }
       // padding block: 0x80, zeros, bit length.  With the constant length of the binary tree the whole
-      // message schedule of this block folds to literals at compile time.
-      w[0] = 0x80000000u;
+      // message schedule of this block is a compile-time table (PadBlock).
+      if constexpr (IC > 0) h.template compress_pad_block<(u32)IC * 256u>();
+      else {
+        w[0] = 0x80000000u;
 #pragma unroll
-      for (int i = 1; i < 15; i++) w[i] = 0;
-      w[15] = ic * 256u;  // message bits (ic * 32 bytes)
-      h.compress(w);
+        for (int i = 1; i < 15; i++) w[i] = 0;
+        w[15] = ic * 256u;  // message bits (ic * 32 bytes)
+        h.compress(w);
+      }
       uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + (child_off + nchildren + g) * 8);
       uint4_t o0, o1;
       o0.x = bswap32(h.st[0]); o0.y = bswap32(h.st[1]); o0.z = bswap32(h.st[2]); o0.w = bswap32(h.st[3]);

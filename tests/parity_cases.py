@@ -51,6 +51,12 @@ def case_merkle(mk, field, leaf_num, ext, lpn, ic, special=False):
         p = MODULUS[field]
         vals = [0, 1, p - 1, 2**32 % p, 12345678901234567890 % p, 1000100010001 % p, 10203040506070809 % p]
         vals += [v % p for k in range(1, 20) for v in (10**k - 1, 10**k, 10**k + 1, 7 * 10**k)]  # every digit-count boundary
+        # chunk boundaries of the kernels' decimal conversion (estimated quotients by 10^16 / 10^8 / 10^4 with fix-ups)
+        for a in (0, 1, 2, 999, 1000, 1843, 1844):
+            for b in (0, 1, 9999, 10000, 99999999):
+                for c in (0, 1, 9999, 10000, 99999999):
+                    vals.append(a * 10**16 + b * 10**8 + c)
+        vals += [p - 2, 2**63 % p, (2**64 - 2**32) % p, 2**54 - 1, 2**54, 10**16 - 2**22, 10**16 + 2**22 - 1]
         for i, v in enumerate(vals):
             leafs[i % leafs.size] = v % p
     rc, nodes, root = ctx.merkle_commit(leafs, ext, lpn, ic)
