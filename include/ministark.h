@@ -63,6 +63,27 @@ int ms_ext_degree(const ms_ctx* ctx);             /* 2 (Goldilocks) / 4 (BabyBea
 int ms_set_stream(ms_ctx* ctx, void* hip_stream); /* run on a caller-owned hipStream_t (NULL: back to the ctx's own) */
 int ms_synchronize(ms_ctx* ctx);
 
+/* ---- one proof sharded over the GPUs of a node (no reference counterpart) ----
+ * One process per GPU, every rank calls the SAME stage functions with the SAME inputs and gets the same
+ * outputs.  Coefficient-domain work is replicated; the evaluation-domain work of every large commitment
+ * (coset LDE / FRI codeword, leaf hashing, Merkle subtree) is partitioned: rank k evaluates and hashes the
+ * leaf groups j = k (mod world) (a union of cosets of the evaluation domain: no data moves), then
+ *   ALL_TO_ALL   of leaf digests  -> rank r owns the contiguous leaves [r*M/world, (r+1)*M/world) and builds that subtree,
+ *   ALL_GATHER   of the `world` subtree roots -> every rank finishes the top log2(world) levels.
+ * The query phase locates leaves by value on every rank (ALL_REDUCE_MIN of the global index: first match wins,
+ * quirk Q7) and assembles the Merkle paths from their owners (ALL_REDUCE_SUM over disjoint bytes).
+ * The library calls `fn` at those points with the payload in the caller-provided device buffers:
+ *   ALL_TO_ALL         send = world chunks of `bytes` (chunk p goes to rank p), recv = world chunks (chunk p from rank p)
+ *   ALL_GATHER         send = `bytes`, recv = world * `bytes` in rank order
+ *   ALL_REDUCE_MIN_U64 / ALL_REDUCE_SUM_U8   in place on send, `bytes` in total
+ * The library has synchronised its stream before the call; `fn` returns 0 once the result is visible to the device.
+ * Commitments with fewer than MS_SHARD_MIN_LEAVES (env, default 32768) leaf groups stay replicated.
+ * world must be a power of two; world = 1 switches sharding off.  ms_lde_read / ms_fri_round_codeword_read
+ * are not available for sharded commitments (each rank holds its part only). */
+typedef enum { MS_XCHG_ALL_TO_ALL = 0, MS_XCHG_ALL_GATHER = 1, MS_XCHG_ALL_REDUCE_MIN_U64 = 2, MS_XCHG_ALL_REDUCE_SUM_U8 = 3 } ms_xchg_op;
+typedef int (*ms_exchange_fn)(void* user, int op, size_t bytes);
+int ms_set_shard(ms_ctx* ctx, int rank, int world, void* d_send, void* d_recv, size_t cap_bytes, ms_exchange_fn fn, void* user);
+
 /* ---- src/util.rs:4-44, src/starks.rs:268-332 (host-only config math) ----- */
 int ms_is_power_of_two(uint64_t n);
 long ms_logarithm_of_two_k(uint64_t n, uint64_t base); /* -1: not a power of 2, -2: not a power of base */

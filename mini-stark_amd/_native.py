@@ -63,6 +63,10 @@ def load_library(path=None):
     return L
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_size_t)  # ms_exchange_fn
+XCHG_ALL_TO_ALL, XCHG_ALL_GATHER, XCHG_ALL_REDUCE_MIN_U64, XCHG_ALL_REDUCE_SUM_U8 = 0, 1, 2, 3
+
+
 def _u64(a):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     return a, a.ctypes.data_as(_u64p)
@@ -117,6 +121,13 @@ class Context:
 
     def synchronize(self):
         self.check(self.L.ms_synchronize(self.h))
+
+    def set_shard(self, rank, world, send_ptr, recv_ptr, cap_bytes, callback):
+        """ms_set_shard: one proof over `world` ranks.  `callback(op, nbytes) -> int` runs the collective on the exchange
+        buffers (mini_stark_amd.dist.ShardExchange does it with torch.distributed)."""
+        self._xchg_cb = EXCHANGE_FN(lambda user, op, nbytes: int(callback(int(op), int(nbytes)))) if callback is not None else EXCHANGE_FN(0)
+        self.L.ms_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, EXCHANGE_FN, C.c_void_p]
+        self.check(self.L.ms_set_shard(self.h, rank, world, send_ptr, recv_ptr, cap_bytes, self._xchg_cb, None))
 
     # ---- Stark::prove stages ---------------------------------------------------
     def trace_commit(self, trace, lpn):

@@ -464,4 +464,87 @@ template <class F, int E> struct PathKernel {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Sharded trees (ms_set_shard).  After the all-to-all, recv chunk k holds the digests of the leaves
+// p = k + W*q (q < per) of this rank's contiguous range: interleave them into subtree leaf order.
+struct InterleaveDigestsKernel {
+  static constexpr int THREADS = 256;
+  struct Params { const uint4_t* recv; uint4_t* leaves; size_t per /* digests per chunk */; u32 W; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
+    const size_t t = (size_t)bx * nthreads + tid;   // half-digest index in subtree leaf order
+    const size_t pidx = t >> 1, half = t & 1;
+    if (pidx >= p.per * p.W) return;
+    const size_t k = pidx % p.W, q = pidx / p.W;
+    p.leaves[t] = p.recv[(k * p.per + q) * 2 + half];
+  }
+};
+// byte copies described by a device job table (gathering Merkle paths from the exchange buffer into the proof blob)
+struct CopyJob { const unsigned char* src; unsigned char* dst; size_t bytes; };
+struct CopyJobsKernel {
+  static constexpr int THREADS = 64;
+  struct Params { const CopyJob* jobs; u32 njobs; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
+    if ((u32)bx >= p.njobs) return;
+    const CopyJob j = p.jobs[bx];
+    for (size_t i = (size_t)tid; i < j.bytes; i += (size_t)nthreads) j.dst[i] = j.src[i];
+  }
+};
+// MerklePath of a sharded binary tree, same layout as PathKernel; every byte is written by exactly ONE rank
+// (the others leave zeros; the ranks' buffers are then summed):
+//   leaf index, leaf values, level count : the rank that evaluated the leaf group  (group % W)
+//   sibling pairs inside a subtree       : the rank that owns the contiguous range (group / Mloc)
+//   sibling pairs of the replicated top  : rank 0
+template <class F, int E> struct ShardPathJob {
+  const typename F::T* cw; size_t limb_stride, m;   // local codeword: limb l, coset t, index q at cw[l*limb_stride + t*m + q]
+  const u32* sub; const u32* top; size_t Mloc;      // subtree nodes (level-major, Mloc leaves) / top nodes (level-major, W subtree roots)
+  u32 lpn, W, rank, nlevels /* log2(M) */;
+  const unsigned long long* idx;                    // global element index of the opened leaf
+  unsigned char* out;
+};
+template <class F, int E> struct ShardPathKernel {
+  typedef typename F::T T;
+  static constexpr int THREADS = 64;
+  struct Params { const ShardPathJob<F, E>* jobs; u32 njobs; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& pp, int bx, int, int tid, int nthreads, unsigned char*) {
+    const u32 t = (u32)bx * nthreads + tid;
+    if (t >= pp.njobs) return;
+    const ShardPathJob<F, E>& p = pp.jobs[t];
+    const size_t li = (size_t)*p.idx;
+    if (li == (size_t)~0ULL) return;
+    u64* o = reinterpret_cast<u64*>(p.out);
+    const size_t grp = li / p.lpn;
+    if (grp % p.W == p.rank) {
+      const size_t q = grp / p.W;
+      o[0] = li;
+      for (u32 i = 0; i < p.lpn; i++)
+        for (int k = 0; k < E; k++) o[1 + i * E + k] = F::to_u64(p.cw[(size_t)k * p.limb_stride + (size_t)i * p.m + q]);
+      o[1 + p.lpn * E] = p.nlevels;
+    }
+    u32* o32 = reinterpret_cast<u32*>(o + 2 + p.lpn * E);
+    u32 sub_levels = 0; while (((size_t)1 << sub_levels) < p.Mloc) sub_levels++;
+    const size_t owner = grp / p.Mloc;
+    size_t level_off = 0, level_n = p.Mloc;
+    for (u32 l = 0; l < sub_levels; l++) {
+      if (owner == p.rank) {
+        const size_t cur = grp >> l, s = cur - (cur & 1) - owner * level_n;
+        const u32* src = p.sub + (level_off + s) * 8;
+        for (u32 i = 0; i < 16; i++) o32[(size_t)l * 16 + i] = src[i];
+      }
+      level_off += level_n; level_n >>= 1;
+    }
+    level_off = 0; level_n = p.W;
+    for (u32 l = sub_levels; l < p.nlevels; l++) {
+      if (p.rank == 0) {
+        const size_t cur = grp >> l, s = cur - (cur & 1);
+        const u32* src = p.top + (level_off + s) * 8;
+        for (u32 i = 0; i < 16; i++) o32[(size_t)l * 16 + i] = src[i];
+      }
+      level_off += level_n; level_n >>= 1;
+    }
+  }
+};
+
 }  // namespace msmerkle

@@ -57,6 +57,7 @@ struct CtxBase {
   virtual void bind_device() const = 0;  // HIP's current device is per host thread: every entry point binds the context's device
   virtual int set_stream(void* s) = 0;
   virtual int synchronize() = 0;
+  virtual int set_shard(int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) = 0;
   virtual int trace_commit(const u64* trace, bool on_device, size_t N, size_t w, size_t lpn, u8* root) = 0;
   virtual int interpolate() = 0;
   virtual int polys_lincomb(const u64* s, const int* idx, int k) = 0;
@@ -99,6 +100,25 @@ template <class F> struct Ctx : CtxBase {
   msrt::Stream* own_stream = nullptr;
   msrt::Stream* stream = nullptr;
   void* pinned = nullptr; size_t pinned_cap = 0;
+
+  // ---- one proof sharded over `sh_world` ranks (ms_set_shard; include/ministark.h)
+  int sh_rank = 0, sh_world = 1;
+  u8* xs = nullptr; u8* xr = nullptr; size_t xcap = 0;   // caller-owned exchange buffers (device)
+  ms_exchange_fn xfn = nullptr; void* xuser = nullptr;
+  size_t shard_min_leaves = 32768;                        // MS_SHARD_MIN_LEAVES: smaller commitments stay replicated
+  int exchange(int op, size_t bytes) {
+    CK(msrt::sync(stream));
+    if (xfn(xuser, op, bytes)) return fail(MS_ERR_HIP, "exchange callback failed");
+    return 0;
+  }
+  bool shardable(size_t leaf_groups) const { return sh_world > 1 && leaf_groups >= shard_min_leaves && leaf_groups >= (size_t)sh_world * (size_t)sh_world; }
+  int set_shard(int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) override {
+    if (world < 1 || !is_pow2((u64)world) || rank < 0 || rank >= world) return fail(MS_ERR_ARG, "set_shard: world must be a power of two and 0 <= rank < world");
+    if (world > 1 && (!d_send || !d_recv || !fn || cap < 4096)) return fail(MS_ERR_ARG, "set_shard: exchange buffers / callback missing");
+    sh_rank = rank; sh_world = world; xs = reinterpret_cast<u8*>(d_send); xr = reinterpret_cast<u8*>(d_recv); xcap = cap; xfn = fn; xuser = user;
+    have_lde = false; nrounds_done = 0; blob_size = 0;
+    return MS_OK;
+  }
 
   int fail_rt(int e, const char* what) { err = std::string("runtime error ") + std::to_string(e) + " in " + what + ": " + msrt::last_error_string(); return MS_ERR_HIP; }
   int fail(int code, const char* msg) { err = msg; return code; }
@@ -341,7 +361,9 @@ template <class F> struct Ctx : CtxBase {
   }
 
   // ------------------------------------------------------------------ Merkle
-  struct TreeShape { size_t leaf_num = 0, lpn = 0, ic = 0, levels = 0, nodes = 0; };
+  // sharded (ms_set_shard): this rank holds the subtree over leaf groups [rank*Mloc, (rank+1)*Mloc) followed by the replicated top
+  // (world subtree roots and the levels above); local_nodes = nodes held here, root last in both cases
+  struct TreeShape { size_t leaf_num = 0, lpn = 0, ic = 0, levels = 0, nodes = 0, local_nodes = 0, Mloc = 0; bool sharded = false; };
   // src/merkle.rs:89-118 (shape checks and node count)
   int tree_shape(size_t leaf_num, size_t lpn, size_t ic, TreeShape* ts) {
     if (lpn == 0 || ic < 2 || !is_pow2(ic)) return fail(MS_ERR_SHAPE, "merkle: bad leafs_per_node / inner_children");
@@ -353,7 +375,7 @@ template <class F> struct Ctx : CtxBase {
     ts->leaf_num = leaf_num; ts->lpn = lpn; ts->ic = ic; ts->levels = (size_t)lg + 1;
     size_t total = 0, m = node_num;
     for (;;) { total += m; if (m == 1) break; m /= ic; }
-    ts->nodes = total;
+    ts->nodes = total; ts->local_nodes = total; ts->Mloc = 0; ts->sharded = false;
     return 0;
   }
   template <int EL>
@@ -365,29 +387,60 @@ template <class F> struct Ctx : CtxBase {
     const size_t blocks = (lp.ngroups + msmerkle::THREADS - 1) / msmerkle::THREADS;
     next_bytes = (double)lp.ngroups * (ts.lpn * EL * sizeof(T) + 32);
     CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, (unsigned)blocks, 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
-    size_t child_off = 0, nchildren = lp.ngroups;
+    RQ(inner_levels(nodes.as<u32>(), lp.ngroups, ts.ic));
+    return 0;
+  }
+  // inner levels above `nchildren` digests at nodes[0..): level-major, root last (merkle.rs:131-140)
+  int inner_levels(u32* nodes, size_t nchildren, size_t ic) {
+    size_t child_off = 0;
     while (nchildren > 1) {
       msmerkle::InnerHashKernel::Params ip;
-      ip.nodes = nodes.as<u32>(); ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ts.ic;
-      const size_t nparents = nchildren / ts.ic;
+      ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic;
+      const size_t nparents = nchildren / ic;
       if (nparents <= 4 * (size_t)msmerkle::THREADS) {  // fused tree top: one workgroup walks the remaining levels
-        u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ts.ic) nl++;
+        u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ic) nl++;
         ip.nlevels = nl;
         next_bytes = (double)nchildren * 32 * 2;
-        if (ts.ic == 2) CK(run<msmerkle::InnerHashKernel2>(K_INNER_HASH, 1, 1, msmerkle::THREADS, 0, ip));
+        if (ic == 2) CK(run<msmerkle::InnerHashKernel2>(K_INNER_HASH, 1, 1, msmerkle::THREADS, 0, ip));
         else CK(run<msmerkle::InnerHashKernel>(K_INNER_HASH, 1, 1, msmerkle::THREADS, 0, ip));
         break;
       }
       ip.nlevels = 1;
-      next_bytes = (double)nparents * (ts.ic * 32 + 32);
-      if (ts.ic == 2) CK(run<msmerkle::InnerHashKernel2>(K_INNER_HASH, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
+      next_bytes = (double)nparents * (ic * 32 + 32);
+      if (ic == 2) CK(run<msmerkle::InnerHashKernel2>(K_INNER_HASH, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
       else CK(run<msmerkle::InnerHashKernel>(K_INNER_HASH, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
       child_off += nchildren; nchildren = nparents;
     }
     return 0;
   }
+  // Sharded MerkleTree::new over a binary tree of M = leaf_num/lpn leaf groups, of which this rank hashes the groups
+  // j = rank + W*i found at local group index i of the view (base, strides): digest all-to-all, subtree, root all-gather, top.
+  template <int EL>
+  int tree_build_sharded(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, TreeShape& ts, DevBuf& nodes) {
+    const size_t W = (size_t)sh_world, M = ts.leaf_num / ts.lpn, Mloc = M / W, per = Mloc / W;
+    if (ts.ic != 2 || per == 0) return fail(MS_ERR_STATE, "sharded tree needs a binary tree with at least world^2 leaf groups");
+    if (Mloc * 32 > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small for the sharded commitment (need 32 * leaf groups / world bytes)");
+    const size_t sub_nodes = 2 * Mloc - 1, top_nodes = 2 * W - 1;
+    if (nodes.ensure((sub_nodes + top_nodes) * 32)) return fail(MS_ERR_NOMEM, "merkle nodes");
+    typename msmerkle::LeafHashKernel<F, EL>::Params lp;
+    lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
+    lp.width = width; lp.lpn = (u32)ts.lpn; lp.zero_as_empty = zae; lp.ngroups = Mloc; lp.nodes = reinterpret_cast<u32*>(xs);
+    next_bytes = (double)lp.ngroups * (ts.lpn * EL * sizeof(T) + 32);
+    CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, grid1(Mloc, msmerkle::THREADS), 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
+    RQ(exchange(MS_XCHG_ALL_TO_ALL, per * 32));
+    msmerkle::InterleaveDigestsKernel::Params ik{reinterpret_cast<const msmerkle::uint4_t*>(xr), reinterpret_cast<msmerkle::uint4_t*>(nodes.p), per, (u32)W};
+    CK(run<msmerkle::InterleaveDigestsKernel>(K_IO, grid1(Mloc * 2, msmerkle::InterleaveDigestsKernel::THREADS), 1, msmerkle::InterleaveDigestsKernel::THREADS, 0, ik));
+    RQ(inner_levels(nodes.as<u32>(), Mloc, 2));
+    CK(msrt::d2d(xs, nodes.as<u8>() + (sub_nodes - 1) * 32, 32, stream));
+    RQ(exchange(MS_XCHG_ALL_GATHER, 32));
+    u8* top = nodes.as<u8>() + sub_nodes * 32;
+    CK(msrt::d2d(top, xr, W * 32, stream));
+    RQ(inner_levels(reinterpret_cast<u32*>(top), W, 2));
+    ts.sharded = true; ts.Mloc = Mloc; ts.local_nodes = sub_nodes + top_nodes;
+    return 0;
+  }
   int read_root(const DevBuf& nodes, const TreeShape& ts, u8* root) {
-    CK(msrt::d2h(pinned, nodes.as<u8>() + (ts.nodes - 1) * 32, 32, stream));
+    CK(msrt::d2h(pinned, nodes.as<u8>() + (ts.local_nodes - 1) * 32, 32, stream));
     CK(msrt::sync(stream));
     memcpy(root, pinned, 32);
     return 0;
@@ -403,7 +456,7 @@ template <class F> struct Ctx : CtxBase {
   TreeShape trace_ts, lde_ts;
   size_t lde_c = 0;
 
-  struct Round { DevBuf poly, cw, nodes; size_t cap = 0, ncoef = 0, D = 0; TreeShape ts; };
+  struct Round { DevBuf poly, cw, nodes; size_t cap = 0, ncoef = 0, D = 0; TreeShape ts; size_t m = 0; /* sharded: local codeword = limbs x 2 cosets x m */ };
   std::vector<Round*> rounds; size_t nrounds_done = 0, fri_rounds = 0, fri_blowup = 0;
   bool have_deep = false; XE cur_z; XE cur_B[2];
   DevBuf d_folded, d_sh, d_blob, d_tabs, d_targets, d_idx, d_deg;
@@ -431,6 +484,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MIN")) ntt_fast_min = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
+    if (const char* e = getenv("MS_SHARD_MIN_LEAVES")) { long v = atol(e); if (v >= 1) shard_min_leaves = (size_t)v; }
     CK(msrt::set_device(dev));
     CK(msrt::stream_create(&own_stream));
     stream = own_stream;
@@ -578,6 +632,43 @@ template <class F> struct Ctx : CtxBase {
           RQ(lincomb_into(d_lde.as<T>(), L_, L_, poly_lin[i].s.data(), poly_lin[i].idx.data(), (int)poly_lin[i].idx.size(), (int)i, d_lde.as<T>() + i * L_));
     return 0;
   }
+  // Evaluations of `batch` polynomials (ncoef coefficients each) on this rank's share of the size-2^log_D domain shift*<w_D>:
+  // the rows g*(rank + W*i) + t (t < g, i < m = D/(g*W)) — g cosets of <w_m> — land at dst[b*dst_bstride + t*m + i].
+  int coset_eval(const T* coef, size_t coef_bstride, size_t ncoef, int log_D, T shift, size_t g, T* dst, size_t dst_bstride, size_t batch) {
+    if (batch == 0) return 0;
+    const size_t D = (size_t)1 << log_D, W = (size_t)sh_world, m = D / (g * W);
+    if (m == 0) return fail(MS_ERR_STATE, "domain too small to shard");
+    if (d_coef.ensure(batch * m * sizeof(T))) return fail(MS_ERR_NOMEM, "coset scratch");
+    const T wD = f_root_of_unity<F>(log_D);
+    typedef msntt::CosetFoldKernel<F> CF;
+    const size_t lim = ncoef < m ? ncoef : m;
+    for (size_t t = 0; t < g; t++) {
+      const T zeta = F::mul(shift, f_pow<F>(wD, (u64)(g * (size_t)sh_rank + t)));
+      typename CF::Params cp;
+      cp.src = coef; cp.dst = d_coef.as<T>(); cp.src_bstride = coef_bstride; cp.dst_bstride = m; cp.n = ncoef; cp.m = m;
+      cp.s = zeta; cp.s_step = f_pow<F>(zeta, CF::THREADS); cp.sm = f_pow<F>(zeta, (u64)m);
+      CK(run<CF>(K_SCALE_POW, grid1(lim, CF::THREADS * CF::ITEMS), (unsigned)batch, CF::THREADS, 0, cp));
+      RQ(ntt_run(ctz64(m), false, d_coef.as<T>(), m, lim, dst + t * m, dst_bstride, batch));
+    }
+    return 0;
+  }
+  // lde_compute for a sharded proof: column i of the local LDE (rows rank + W*j) at d_lde + i*m, m = L/W
+  int lde_compute_sharded(size_t blowup_, u64 shift) {
+    const size_t c = (size_t)npolys, L_ = N * blowup_, m = L_ / (size_t)sh_world;
+    if (d_lde.ensure(c * m * sizeof(T))) return fail(MS_ERR_NOMEM, "lde");
+    for (size_t i = 0; i < c;) {
+      if (lde_linear && !poly_lin[i].idx.empty()) { i++; continue; }
+      size_t j = i;
+      while (j < c && !(lde_linear && !poly_lin[j].idx.empty())) j++;
+      RQ(coset_eval(d_polys.as<T>() + i * N, N, N, ctz64(L_), F::from_u64(shift), 1, d_lde.as<T>() + i * m, m, j - i));
+      i = j;
+    }
+    if (lde_linear)
+      for (size_t i = 0; i < c; i++)
+        if (!poly_lin[i].idx.empty())
+          RQ(lincomb_into(d_lde.as<T>(), m, m, poly_lin[i].s.data(), poly_lin[i].idx.data(), (int)poly_lin[i].idx.size(), (int)i, d_lde.as<T>() + i * m));
+    return 0;
+  }
   int lde_commit(size_t blowup_, u64 shift, size_t lpn, u8* root) override {
     if (!have_polys) return fail(MS_ERR_STATE, "lde_commit before interpolate");
     if (!root || !blowup_ || !is_pow2(blowup_) || shift == 0 || shift >= F::P) return fail(MS_ERR_ARG, "bad blowup/shift");
@@ -586,9 +677,14 @@ template <class F> struct Ctx : CtxBase {
     const size_t c = (size_t)npolys;
     TreeShape ts;
     RQ(tree_shape(L_ * c, lpn, 2, &ts));
-    RQ(lde_compute(blowup_, shift));
     L = L_; blowup = blowup_; lde_c = c;
-    RQ((tree_build<1>(d_lde.as<T>(), L, 1, 0, (u32)c, ts, d_lde_nodes)));
+    if (lpn == c && shardable(L_)) {  // one LDE row per leaf group: rank k evaluates and hashes the rows k (mod world)
+      RQ(lde_compute_sharded(blowup_, shift));
+      RQ((tree_build_sharded<1>(d_lde.as<T>(), L / (size_t)sh_world, 1, 0, (u32)c, ts, d_lde_nodes)));
+    } else {
+      RQ(lde_compute(blowup_, shift));
+      RQ((tree_build<1>(d_lde.as<T>(), L, 1, 0, (u32)c, ts, d_lde_nodes)));
+    }
     lde_ts = ts;
     RQ(read_root(d_lde_nodes, ts, root));
     have_lde = true;
@@ -600,6 +696,7 @@ template <class F> struct Ctx : CtxBase {
   }
   int lde_read(u64* out) override {
     if (!have_lde || !out) return fail(MS_ERR_STATE, "lde_read");
+    if (lde_ts.sharded) return fail(MS_ERR_STATE, "lde_read: the LDE of a sharded proof is distributed over the ranks");
     const size_t tot = L * lde_c;
     if (d_io.ensure(tot * 8)) return fail(MS_ERR_NOMEM, "io");
     typename mspoly::TransposeOutKernel<F>::Params p{d_lde.as<T>(), d_io.as<u64>(), L, lde_c, L};
@@ -689,6 +786,16 @@ template <class F> struct Ctx : CtxBase {
   int round_commit(Round* r, size_t ncoef_in, int nonzero_limbs = E) {
     if (ctz64(r->D) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "FRI domain larger than the field's two-adicity");
     RQ(tree_shape(r->D, 2, 2, &r->ts));  // starks.rs:290-295: leafs_per_node 2, inner_children 2
+    r->m = 0;
+    if (shardable(r->D / 2)) {  // leaf group j = codeword elements 2j, 2j+1: rank k owns the groups k (mod world) = two cosets of size m
+      const size_t m = r->D / (2 * (size_t)sh_world);
+      r->m = m;
+      if (r->cw.ensure(2 * m * E * sizeof(T))) return fail(MS_ERR_NOMEM, "codeword");
+      RQ(coset_eval(r->poly.template as<T>(), r->cap, ncoef_in, ctz64(r->D), F::from_u64(1), 2, r->cw.template as<T>(), 2 * m, (size_t)nonzero_limbs));
+      if (nonzero_limbs < E) CK(msrt::memset_dev(r->cw.template as<T>() + (size_t)nonzero_limbs * 2 * m, 0, (size_t)(E - nonzero_limbs) * 2 * m * sizeof(T), stream));
+      RQ((tree_build_sharded<E>(r->cw.template as<T>(), m, 1, 2 * m, 2, r->ts, r->nodes)));
+      return 0;
+    }
     if (r->cw.ensure(r->D * E * sizeof(T))) return fail(MS_ERR_NOMEM, "codeword");
     RQ(ntt_run(ctz64(r->D), false, r->poly.template as<T>(), r->cap, ncoef_in, r->cw.template as<T>(), r->D, (size_t)nonzero_limbs));  // fri.rs:350
     if (nonzero_limbs < E) CK(msrt::memset_dev(r->cw.template as<T>() + (size_t)nonzero_limbs * r->D, 0, (size_t)(E - nonzero_limbs) * r->D * sizeof(T), stream));
@@ -704,7 +811,7 @@ template <class F> struct Ctx : CtxBase {
       CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
     }
     CK(msrt::d2h(pinned, dres, 8, stream));
-    if (r) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, r->nodes.template as<u8>() + (r->ts.nodes - 1) * 32, 32, stream));
+    if (r) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, r->nodes.template as<u8>() + (r->ts.local_nodes - 1) * 32, 32, stream));
     CK(msrt::sync(stream));
     *ncoef = (size_t)(*reinterpret_cast<unsigned long long*>(pinned));
     if (r && root) memcpy(root, reinterpret_cast<u8*>(pinned) + 64, 32);
@@ -851,6 +958,7 @@ template <class F> struct Ctx : CtxBase {
   }
   int fri_round_codeword_read(int r, u64* out) override {
     if (r < 0 || (size_t)r >= nrounds_done || !out) return fail(MS_ERR_ARG, "round index");
+    if (rounds[r]->ts.sharded) return fail(MS_ERR_STATE, "codeword_read: the codeword of a sharded round is distributed over the ranks");
     return download_widen(rounds[r]->cw.template as<T>(), rounds[r]->D, rounds[r]->D, E, out);
   }
 
@@ -927,20 +1035,38 @@ template <class F> struct Ctx : CtxBase {
     // ---- find-first and path jobs
     typedef mspoly::FindJob<F, E> FJ;
     typedef msmerkle::PathJob<F, E> PJ;
-    std::vector<FJ> fjobs(W); std::vector<PJ> pjobs(W * nq * 2);
+    // Sharded proof (ms_set_shard): paths are staged in the exchange buffer — every byte written by exactly one rank
+    // (replicated rounds: rank 0), summed over the ranks, then copied into the blob.
+    typedef msmerkle::ShardPathJob<F, E> SPJ;
+    const bool shard = sh_world > 1;
+    std::vector<FJ> fjobs(W); std::vector<PJ> pjobs; std::vector<SPJ> sjobs; std::vector<msmerkle::CopyJob> cjobs;
+    size_t stage_bytes = 0;
     for (size_t i = 0; i < W; i++) {
       Round* pr = rounds[i];
-      fjobs[i] = FJ{pr->cw.template as<T>(), pr->D, pr->D, d_tg + i * 2 * nq * E, 2 * nq, d_ix + i * 2 * nq};
-      for (int t = 0; t < 2 * nq; t++)
-        pjobs[i * 2 * nq + t] = PJ{pr->cw.template as<T>(), pr->D, pr->nodes.template as<u32>(), pr->D, 2, 2, (u32)(pr->ts.levels - 1), d_ix + i * 2 * nq + t,
-                                   blob + path_off[(i * nq + t / 2) * 2 + (t & 1)]};
+      const size_t nlev = pr->ts.levels - 1, path_bytes = 8 + 2 * E * 8 + 8 + nlev * 2 * 32;
+      if (pr->ts.sharded) {
+        fjobs[i] = FJ{pr->cw.template as<T>(), 2 * pr->m, 2 * pr->m, d_tg + i * 2 * nq * E, 2 * nq, d_ix + i * 2 * nq, 2, (u32)sh_world, (u32)sh_rank, pr->m};
+      } else fjobs[i] = FJ{pr->cw.template as<T>(), pr->D, pr->D, d_tg + i * 2 * nq * E, 2 * nq, d_ix + i * 2 * nq, 0, 0, 0, 0};
+      for (int t = 0; t < 2 * nq; t++) {
+        u8* dst = blob + path_off[(i * nq + t / 2) * 2 + (t & 1)];
+        u8* out = dst;
+        if (shard) { out = xs + stage_bytes; cjobs.push_back(msmerkle::CopyJob{out, dst, path_bytes}); stage_bytes += path_bytes; }
+        if (pr->ts.sharded)
+          sjobs.push_back(SPJ{pr->cw.template as<T>(), 2 * pr->m, pr->m, pr->nodes.template as<u32>(), pr->nodes.template as<u32>() + (2 * pr->ts.Mloc - 1) * 8, pr->ts.Mloc,
+                              2, (u32)sh_world, (u32)sh_rank, (u32)nlev, d_ix + i * 2 * nq + t, out});
+        else if (!shard || sh_rank == 0)
+          pjobs.push_back(PJ{pr->cw.template as<T>(), pr->D, pr->nodes.template as<u32>(), pr->D, 2, 2, (u32)nlev, d_ix + i * 2 * nq + t, out});
+      }
     }
+    if (shard && (stage_bytes > xcap || W * nq * 2 * 8 > xcap)) return fail(MS_ERR_NOMEM, "exchange buffers too small for the query phase");
     // ---- one upload: [SH tables][find jobs][path jobs][rec_off][qlen][x1]
     size_t bytes = 0;
     std::vector<size_t> toff(tables.size());
     for (size_t k = 0; k < tables.size(); k++) { toff[k] = bytes; bytes += tables[k].size() * sizeof(SHJ); }
     const size_t off_f = bytes; bytes += fjobs.size() * sizeof(FJ);
     const size_t off_p = bytes; bytes += pjobs.size() * sizeof(PJ);
+    const size_t off_sp = bytes; bytes += sjobs.size() * sizeof(SPJ);
+    const size_t off_cj = bytes; bytes += cjobs.size() * sizeof(msmerkle::CopyJob);
     const size_t off_rec = bytes; bytes += rec_off.size() * sizeof(size_t);
     const size_t off_ql = bytes; bytes += qlen.size() * 8;
     const size_t off_x1 = bytes; bytes += x1h.size() * sizeof(T);
@@ -948,6 +1074,8 @@ template <class F> struct Ctx : CtxBase {
     for (size_t k = 0; k < tables.size(); k++) memcpy(tab.data() + toff[k], tables[k].data(), tables[k].size() * sizeof(SHJ));
     if (!fjobs.empty()) memcpy(tab.data() + off_f, fjobs.data(), fjobs.size() * sizeof(FJ));
     if (!pjobs.empty()) memcpy(tab.data() + off_p, pjobs.data(), pjobs.size() * sizeof(PJ));
+    if (!sjobs.empty()) memcpy(tab.data() + off_sp, sjobs.data(), sjobs.size() * sizeof(SPJ));
+    if (!cjobs.empty()) memcpy(tab.data() + off_cj, cjobs.data(), cjobs.size() * sizeof(msmerkle::CopyJob));
     if (!rec_off.empty()) memcpy(tab.data() + off_rec, rec_off.data(), rec_off.size() * sizeof(size_t));
     memcpy(tab.data() + off_ql, qlen.data(), qlen.size() * 8);
     memcpy(tab.data() + off_x1, x1h.data(), x1h.size() * sizeof(T));
@@ -979,8 +1107,25 @@ template <class F> struct Ctx : CtxBase {
         typename mspoly::FindFirstKernel<F, E>::Params fp; fp.jobs = reinterpret_cast<const FJ*>(dt + off_f) + first_small; fp.inline_job = fjobs[first_small];
         CK(run<mspoly::FindFirstKernel<F, E>>(K_FIND_FIRST, grid1(rounds[first_small]->D, mspoly::THREADS), (unsigned)(W - first_small), mspoly::THREADS, 0, fp));
       }
-      typename msmerkle::PathKernel<F, E>::Params pk{reinterpret_cast<const PJ*>(dt + off_p), (u32)pjobs.size()};
-      CK(run<msmerkle::PathKernel<F, E>>(K_PATH, grid1(pjobs.size(), 64), 1, 64, 0, pk));
+      if (shard) {  // first match over ALL ranks' parts: minimum global index (replicated rounds: every rank holds the same value)
+        CK(msrt::d2d(xs, d_ix, W * nq * 2 * 8, stream));
+        RQ(exchange(MS_XCHG_ALL_REDUCE_MIN_U64, W * nq * 2 * 8));
+        CK(msrt::d2d(d_ix, xs, W * nq * 2 * 8, stream));
+        CK(msrt::memset_dev(xs, 0, stage_bytes, stream));
+      }
+      if (!pjobs.empty()) {
+        typename msmerkle::PathKernel<F, E>::Params pk{reinterpret_cast<const PJ*>(dt + off_p), (u32)pjobs.size()};
+        CK(run<msmerkle::PathKernel<F, E>>(K_PATH, grid1(pjobs.size(), 64), 1, 64, 0, pk));
+      }
+      if (!sjobs.empty()) {
+        typename msmerkle::ShardPathKernel<F, E>::Params sk{reinterpret_cast<const SPJ*>(dt + off_sp), (u32)sjobs.size()};
+        CK(run<msmerkle::ShardPathKernel<F, E>>(K_PATH, grid1(sjobs.size(), 64), 1, 64, 0, sk));
+      }
+      if (shard) {
+        RQ(exchange(MS_XCHG_ALL_REDUCE_SUM_U8, stage_bytes));
+        msmerkle::CopyJobsKernel::Params ck{reinterpret_cast<const msmerkle::CopyJob*>(dt + off_cj), (u32)cjobs.size()};
+        CK(run<msmerkle::CopyJobsKernel>(K_PATH, (unsigned)cjobs.size(), 1, msmerkle::CopyJobsKernel::THREADS, 0, ck));
+      }
       if (W * nq * 2 * 8 > pinned_cap) return fail(MS_ERR_ARG, "too many queries");
       CK(msrt::d2h(pinned, d_ix, W * nq * 2 * 8, stream));
       CK(msrt::sync(stream));
@@ -1129,6 +1274,11 @@ void ms_destroy(ms_ctx* ctx) { if (ctx) { B(ctx)->bind_device(); delete B(ctx); 
 const char* ms_last_error(const ms_ctx* ctx) { return ctx ? B(ctx)->err.c_str() : "null context"; }
 int ms_ext_degree(const ms_ctx* ctx) { return ctx ? B(ctx)->ext_degree() : MS_ERR_ARG; }
 int ms_set_stream(ms_ctx* ctx, void* s) { return ctx ? B(ctx)->set_stream(s) : MS_ERR_ARG; }
+int ms_set_shard(ms_ctx* ctx, int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) {
+  if (!ctx) return MS_ERR_ARG;
+  B(ctx)->bind_device();
+  return B(ctx)->set_shard(rank, world, d_send, d_recv, cap, fn, user);
+}
 int ms_synchronize(ms_ctx* ctx) { if (!ctx) return MS_ERR_ARG; B(ctx)->bind_device(); return B(ctx)->synchronize(); }
 
 int ms_is_power_of_two(uint64_t n) { return is_pow2(n) ? 1 : 0; }

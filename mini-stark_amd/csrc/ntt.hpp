@@ -419,4 +419,30 @@ template <class F> struct ScalePowKernel {
   }
 };
 
+// out[r] = zeta^r * sum_j in[r + j*m] * (zeta^m)^j  (r < min(n, m)): the size-m polynomial that agrees with the n-coefficient
+// input on the coset zeta*<w_m> (x^m == zeta^m there).  Its size-m NTT is the input evaluated on that coset — the part of a
+// size-D evaluation domain one rank of a sharded proof owns (ms_set_shard).  n <= m degenerates to ScalePowKernel.
+template <class F> struct CosetFoldKernel {
+  typedef typename F::T T;
+  static constexpr int THREADS = 256;
+  static constexpr int ITEMS = 16;
+  struct Params { const T* src; T* dst; size_t src_bstride, dst_bstride, n, m; T s, s_step /* s^THREADS */, sm /* s^m */; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int bx, int by, int tid, int, unsigned char*) {
+    size_t r = (size_t)bx * (THREADS * ITEMS) + tid;
+    const size_t lim = p.n < p.m ? p.n : p.m;
+    if (r >= lim) return;
+    const T* src = p.src + (size_t)by * p.src_bstride;
+    T* dst = p.dst + (size_t)by * p.dst_bstride;
+    T pw = f_pow<F>(p.s, r);
+    for (int j = 0; j < ITEMS && r < lim; j++, r += THREADS) {
+      const size_t terms = (p.n - r + p.m - 1) / p.m;  // r + j*m < n
+      T acc = src[r + (terms - 1) * p.m];
+      for (size_t t = terms - 1; t-- > 0;) acc = F::add(F::mul(acc, p.sm), src[r + t * p.m]);
+      dst[r] = F::mul(acc, pw);
+      pw = F::mul(pw, p.s_step);
+    }
+  }
+};
+
 }  // namespace msntt

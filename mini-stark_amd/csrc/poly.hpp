@@ -363,16 +363,21 @@ template <class F, int E> struct DegreeKernel {
     if (r >= p.n) return;
     const size_t j = p.n - 1 - r;
     if ((unsigned long long)(j + 1) <= *reinterpret_cast<volatile unsigned long long*>(p.result)) return;
-    bool nz = false;
+    bool nz = false, nz_next = false;
     for (int l = 0; l < E; l++) nz = nz || (p.src[(size_t)l * p.limb_stride + j] != 0);
-    if (nz) msrt::atomic_max_u64(p.result, (unsigned long long)(j + 1));
+    // only the top of a run of non-zero elements can be the answer: one atomic for a dense polynomial, not one per element
+    if (nz && j + 1 < p.n) for (int l = 0; l < E; l++) nz_next = nz_next || (p.src[(size_t)l * p.limb_stride + j + 1] != 0);
+    if (nz && !nz_next) msrt::atomic_max_u64(p.result, (unsigned long long)(j + 1));
   }
 };
 // per window: result[t] = min index j with leaf_j == target_t (caller fills result with ~0).
 // Jobs batched over blockIdx.y (device table) or one inline job.
+// Sharded codewords (ms_set_shard): the local element j = t*map_m + i is global element map_g*(map_k + map_W*i) + t and the
+// result is the minimum GLOBAL index (map_g = 0: identity).
 template <class F, int E> struct FindJob {
   const typename F::T* src; size_t limb_stride, n;
   const typename F::T* targets /* [nt][E] */; int nt; unsigned long long* result;
+  u32 map_g, map_W, map_k; size_t map_m;
 };
 template <class F, int E> struct FindFirstKernel {
   typedef typename F::T T;
@@ -388,7 +393,11 @@ template <class F, int E> struct FindFirstKernel {
     for (int t = 0; t < p.nt; t++) {
       bool eq = true;
       for (int l = 0; l < E; l++) eq = eq && (v[l] == p.targets[(size_t)t * E + l]);
-      if (eq) msrt::atomic_min_u64(p.result + t, (unsigned long long)j);
+      if (eq) {
+        unsigned long long gj = (unsigned long long)j;
+        if (p.map_g) { const size_t tt = j / p.map_m, ii = j - tt * p.map_m; gj = (unsigned long long)p.map_g * (p.map_k + (unsigned long long)p.map_W * ii) + tt; }
+        msrt::atomic_min_u64(p.result + t, gj);
+      }
     }
   }
 };

@@ -1,9 +1,13 @@
 """One-process-per-GPU helpers (torch.distributed; backend "nccl" is RCCL on ROCm).
 
-The path partitions over independent proofs, so ranks never exchange data inside
-a proof: the only collectives are the timing barrier, a MAX-reduce of the elapsed
-time and an all-gather of each rank's final commitment (outside the timed region).
-Covered on CPU by tests/test_dist_gloo.py (world_size 2, gloo)."""
+Two ways to use N GPUs:
+ * replicas (bench.py default): the path partitions over independent proofs, ranks never exchange data
+   inside a proof; the only collectives are the timing barrier, a MAX-reduce of the elapsed time and an
+   all-gather of each rank's final commitment (outside the timed region).
+ * one proof sharded over the ranks (`ShardExchange`, ms_set_shard): the library partitions the
+   evaluation-domain work of every large commitment and calls back here for the digest all-to-all, the
+   subtree-root all-gather and the two small all-reduces of the query phase (include/ministark.h).
+Covered on CPU by tests/test_dist_gloo.py and tests/test_shard_gloo.py (gloo, world_size 2 and 4)."""
 import os
 
 import torch
@@ -56,3 +60,69 @@ class Group:
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+class ShardExchange:
+    """The exchange callback of ms_set_shard over torch.distributed.
+
+    Owns the two exchange buffers (torch tensors on the group's device: HBM with "nccl" = RCCL, host memory with
+    "gloo" on the kernel-emulation library) and runs the collective the library asks for on views of them.
+    `staged=True` keeps the buffers on the GPU but moves the payload through host tensors for the collective
+    (gloo with GPU contexts: used by the single-GPU rehearsal of the sharded path in tests/test_gpu_parity.py)."""
+
+    def __init__(self, group: Group, ctx, cap_bytes: int, staged: bool = False, buffer_device=None):
+        import torch.distributed as dist
+        self.g, self.dist, self.ctx, self.staged = group, dist, ctx, staged
+        dev = buffer_device if buffer_device is not None else group.device
+        self.send = torch.zeros(cap_bytes, dtype=torch.uint8, device=dev)
+        self.recv = torch.zeros(cap_bytes, dtype=torch.uint8, device=dev)
+        self.calls = {0: 0, 1: 0, 2: 0, 3: 0}
+        self.bytes = 0
+        ctx.set_shard(group.rank, group.world, self.send.data_ptr(), self.recv.data_ptr(), cap_bytes, self._exchange if group.world > 1 else None)
+
+    def _exchange(self, op, nbytes):
+        try:
+            W, d = self.g.world, self.dist
+            self.calls[op] += 1
+            self.bytes += nbytes * (W if op == 0 else 1)
+            if op == 0:      # all-to-all of W chunks
+                a, b = self.send[: nbytes * W], self.recv[: nbytes * W]
+            elif op == 1:    # all-gather
+                a, b = self.send[:nbytes], self.recv[: nbytes * W]
+            else:            # in-place all-reduce on send
+                a, b = self.send[:nbytes], None
+            if self.staged:
+                ha = a.cpu()
+                hb = torch.empty(b.numel(), dtype=torch.uint8) if b is not None else None
+            else:
+                ha, hb = a, b
+            if op == 0:
+                d.all_to_all_single(hb, ha)
+            elif op == 1:
+                d.all_gather_into_tensor(hb, ha) if not self.staged and self.g.backend == "nccl" else self._all_gather(hb, ha, W)
+            elif op == 2:
+                v = ha.view(torch.int64)  # u64 indices < 2^63 or ~0 (= -1): order them as unsigned through a sign flip
+                v ^= torch.iinfo(torch.int64).min
+                d.all_reduce(v, op=d.ReduceOp.MIN)
+                v ^= torch.iinfo(torch.int64).min
+            else:
+                d.all_reduce(ha, op=d.ReduceOp.SUM)
+            if self.staged:
+                if b is not None:
+                    b.copy_(hb)
+                else:
+                    a.copy_(ha)
+            if self.send.is_cuda:
+                torch.cuda.synchronize()
+            return 0
+        except Exception as e:  # the library turns a non-zero return into MS_ERR_HIP
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _all_gather(self, out, mine, W):
+        parts = list(out.view(W, -1).unbind(0))
+        self.dist.all_gather(parts, mine)
+
+    def close(self):
+        self.ctx.set_shard(0, 1, 0, 0, 0, None)

@@ -1,0 +1,35 @@
+"""Worker for tests/test_shard_gloo.py: one rank of ONE proof sharded over the ranks (ms_set_shard), on the
+kernel-emulation library with gloo; every rank checks all stage outputs and the FRI proof bit-for-bit against
+the single-process oracle."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mini_stark_amd as ms  # noqa: E402
+from mini_stark_amd.dist import Group, ShardExchange  # noqa: E402
+import parity_cases as pc  # noqa: E402
+from common import fibonacci_trace_fast  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+field, log_n, blowup = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+os.environ["MS_SHARD_MIN_LEAVES"] = sys.argv[4] if len(sys.argv) > 4 else "16"
+grp = Group("gloo")
+ctx = ms.Context(field, lib_path=os.path.join(ROOT, "tests", "emu", "libministark_emu.so"))
+N = 1 << log_n
+xchg = ShardExchange(grp, ctx, 32 * N * blowup // grp.world + (1 << 20))  # leaf digests of the largest commitment / world + query-phase paths
+trace = fibonacci_trace_fast(field, N)
+got = pc.drive(ctx, field, trace, blowup, 2, seed=11, read_big=False)
+want = pc.drive(orc.Session(field), field, trace, blowup, 2, seed=11, read_big=False)
+assert len(got) == len(want)
+for (ka, va), (kb, vb) in zip(got, want):
+    assert ka == kb and va == vb, f"rank {grp.rank}: stage output {ka} differs from the oracle"
+# the distributed parts are not readable in shard mode
+assert ctx.L.ms_lde_read(ctx.h, None) != 0
+grp.barrier()
+if grp.rank == 0:
+    print(json.dumps({"world": grp.world, "calls": xchg.calls, "bytes": xchg.bytes, "stages": len(got)}), flush=True)
+xchg.close()
+grp.close()
