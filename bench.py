@@ -12,6 +12,10 @@ proof left resident in HBM (PCIe-inclusive rate: see DESIGN.md).  Workload at
 every N: BASELINE.json configs[1] — Fibonacci AIR, Goldilocks, 2^20 trace rows,
 blowup 8, 20 security bits — one independent proof per step per rank (weak
 scaling: the path partitions over proofs; no data-path collective).
+`--mode shard` instead computes ONE proof per step with all ranks together
+(ms_set_shard: RCCL digest all-to-all + root all-gather per large commitment;
+strong scaling) — the latency configuration for single large proofs
+(`--log-rows 24` = BASELINE.json configs[3]).
 
 Rank 0 prints ONE JSON line.  Extra legs (rank 0, outside the timed region):
   roofline     — per-kernel HIP-event timings on the launching stream for the
@@ -42,6 +46,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-rows", type=int, default=18)
     ap.add_argument("--inflight", type=int, default=4, help="independent proofs in flight per GPU (one ms_ctx + HIP stream each); a step = this many proofs")
+    ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
+                    help="replicas (default): every rank proves its own traces, no data-path collective (weak scaling).  shard: ONE proof per step computed by all "
+                         "ranks together (ms_set_shard: coset-partitioned LDE/FRI + leaf hashing, RCCL digest all-to-all and root all-gather; strong scaling)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL, one GPU per rank (the measured configuration).  gloo: rehearsal of the N>1 paths on a box with fewer GPUs than ranks "
+                         "(ranks share GPUs, exchange payloads are staged through host memory)")
     args = ap.parse_args()
 
     import numpy as np
@@ -51,22 +61,30 @@ def main():
     from mini_stark_amd.host import HostStark  # C++ mirror of StarkConfig::new / Stark::prove above the C ABI
 
     from mini_stark_amd.dist import Group
-    grp = Group("nccl")
+    grp = Group(args.backend)
     world, rank, local_rank, dev = grp.world, grp.rank, grp.local_rank, grp.device
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        dev = torch.device("cuda", local_rank)
 
     N = 1 << args.log_rows
     steps = N - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
     import threading
-    C_IN = max(1, args.inflight)
+    shard = args.mode == "shard" and world > 1
+    C_IN = 1 if shard else max(1, args.inflight)
     # one context (own HIP stream, own HBM buffers) per in-flight proof; raises if libministark.so / the GPU is missing
     ctxs = [ms.Context(args.field, device=local_rank) for _ in range(C_IN)]
     ctx = ctxs[0]
-    tts = [fibonacci_air(c, steps, secret_b=2 + rank * C_IN + i) for i, c in enumerate(ctxs)]
+    tts = [fibonacci_air(c, steps, secret_b=2 + (0 if shard else rank * C_IN) + i) for i, c in enumerate(ctxs)]  # shard: every rank holds the same trace
     cfg = StarkConfig(ctx, 20, args.blowup, steps, tts[0].constrain_number())
     starks = [HostStark(c, 20, args.blowup, steps, tts[0].constrain_number()) for c in ctxs]
     d_traces = [torch.from_numpy(t.data.view(np.int64)).to(dev) for t in tts]  # resident in HBM before the timed region
     torch.cuda.synchronize()
     last = [None] * C_IN
+    xchg = None
+    if shard:  # exchange buffers: the leaf digests of the largest commitment (32 B x L / world) + the query phase's Merkle paths
+        from mini_stark_amd.dist import ShardExchange
+        xchg = ShardExchange(grp, ctx, 32 * N * args.blowup // world + (4 << 20), staged=args.backend == "gloo", buffer_device=dev)
 
     def prove_n(i, n):
         for _ in range(n):
@@ -98,17 +116,25 @@ def main():
     final_roots = grp.all_gather_bytes(proof.fri_roots[-1])
     assert len(final_roots) == world
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps * C_IN / elapsed
+    value = (1 if shard else world) * args.steps * C_IN / elapsed
 
     out = {
         "metric": "stark_proofs_per_s", "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
         "dtype": "u64" if args.field == 0 else "u32", "data": "synthetic",
         "config": {"workload": f"Fibonacci AIR, {'Goldilocks' if args.field == 0 else 'BabyBear+Fp4'}, 2^{args.log_rows} trace rows, blowup {args.blowup}, 20 security bits "
                                f"(w=3, c=6, rounds={cfg.rounds}, ood_queries={cfg.constrain_queries}, fri_queries={cfg.fri_queries}); a step = {C_IN} independent proofs in flight per GPU",
                    "proofs_per_step_per_gpu": C_IN, "parallelism": f"replicas x{world} GPUs x {C_IN} in-flight proofs (no data-path collective)"},
     }
+    if shard:
+        out["config"]["parallelism"] = f"one proof sharded over {world} GPUs (ms_set_shard): digest all-to-all + root all-gather per large commitment over RCCL"
+        out["config"]["workload"] = out["config"]["workload"].split("; a step")[0] + f"; a step = 1 proof computed by {world} ranks together"
+        out["config"]["proofs_per_step_per_gpu"] = 1.0 / world
+        out["exchange"] = {"collective_calls_per_rank": {n: xchg.calls[i] for i, n in enumerate(["all_to_all", "all_gather", "all_reduce_min", "all_reduce_sum"])},
+                           "bytes_through_callback_per_rank": xchg.bytes, "proofs": args.steps + args.warmup}
 
+    if shard and rank != 0:
+        step()  # the roofline leg's extra proof is collective in shard mode
     if rank == 0:
         # ---- roofline leg: per-kernel HIP events on the launching stream, one extra (untimed) proof
         buf = C.create_string_buffer(1 << 14)

@@ -435,8 +435,9 @@ template <class F> struct CosetFoldKernel {
     const T* src = p.src + (size_t)by * p.src_bstride;
     T* dst = p.dst + (size_t)by * p.dst_bstride;
     T pw = f_pow<F>(p.s, r);
+    const size_t full = p.n / p.m, rem = p.n - full * p.m;  // uniform: r < rem has one more term
     for (int j = 0; j < ITEMS && r < lim; j++, r += THREADS) {
-      const size_t terms = (p.n - r + p.m - 1) / p.m;  // r + j*m < n
+      const size_t terms = full + (r < rem ? 1 : 0);  // r + t*m < n
       T acc = src[r + (terms - 1) * p.m];
       for (size_t t = terms - 1; t-- > 0;) acc = F::add(F::mul(acc, p.sm), src[r + t * p.m]);
       dst[r] = F::mul(acc, pw);

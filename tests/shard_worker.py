@@ -1,5 +1,5 @@
-"""Worker for tests/test_shard_gloo.py: one rank of ONE proof sharded over the ranks (ms_set_shard), on the
-kernel-emulation library with gloo; every rank checks all stage outputs and the FRI proof bit-for-bit against
+"""Worker for tests/test_shard_gloo.py (and the GPU rehearsal in tests/test_gpu_parity.py): one rank of ONE proof
+sharded over the ranks (ms_set_shard), on the kernel-emulation library (or, with "gpu", the HIP library) with gloo; every rank checks all stage outputs and the FRI proof bit-for-bit against
 the single-process oracle."""
 import json
 import os
@@ -16,10 +16,17 @@ from oracle import oracle as orc  # noqa: E402
 
 field, log_n, blowup = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 os.environ["MS_SHARD_MIN_LEAVES"] = sys.argv[4] if len(sys.argv) > 4 else "16"
+on_gpu = len(sys.argv) > 5 and sys.argv[5] == "gpu"   # the real HIP library, all ranks on GPU 0, payloads staged through host tensors for gloo
 grp = Group("gloo")
-ctx = ms.Context(field, lib_path=os.path.join(ROOT, "tests", "emu", "libministark_emu.so"))
 N = 1 << log_n
-xchg = ShardExchange(grp, ctx, 32 * N * blowup // grp.world + (1 << 20))  # leaf digests of the largest commitment / world + query-phase paths
+cap = 32 * N * blowup // grp.world + (1 << 20)  # leaf digests of the largest commitment / world + query-phase paths
+if on_gpu:
+    import torch
+    ctx = ms.Context(field)
+    xchg = ShardExchange(grp, ctx, cap, staged=True, buffer_device=torch.device("cuda", 0))
+else:
+    ctx = ms.Context(field, lib_path=os.path.join(ROOT, "tests", "emu", "libministark_emu.so"))
+    xchg = ShardExchange(grp, ctx, cap)
 trace = fibonacci_trace_fast(field, N)
 got = pc.drive(ctx, field, trace, blowup, 2, seed=11, read_big=False)
 want = pc.drive(orc.Session(field), field, trace, blowup, 2, seed=11, read_big=False)

@@ -174,3 +174,20 @@ def test_general_closure_path(mk, field):
 @pytest.mark.parametrize("field,ext,lpn,n", [(0, 1, 2, 64), (0, 1, 4, 64), (0, 2, 2, 32), (1, 4, 2, 16), (1, 1, 8, 4096)])
 def test_merkle_prove_by_value(mk, field, ext, lpn, n):
     pc.case_merkle_prove(mk, field, n, ext, lpn)
+
+
+@pytest.mark.parametrize("world,field,log_n", [(2, 0, 12), (4, 1, 11)])
+def test_sharded_proof_on_gpu(world, field, log_n):
+    """ms_set_shard on the real HIP kernels: `world` ranks share this box's GPU (gloo, payloads staged through host
+    memory), each proves its share of ONE proof; every rank checks all outputs against the oracle (tests/shard_worker.py)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29950 + world), os.path.join(here, "shard_worker.py"), str(field), str(log_n), "8", "64", "gpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    calls = {int(k): v for k, v in res["calls"].items()}
+    assert res["world"] == world and calls[0] >= 3 and calls[2] == 1 and calls[3] == 1
