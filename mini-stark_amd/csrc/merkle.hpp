@@ -23,6 +23,9 @@
 namespace msmerkle {
 
 constexpr int THREADS = 256;
+constexpr int OVF_WORDS = 2;    // deferred pad-only block entry: leaf group, message bits (the SHA-256 state waits in the digest slot)
+constexpr int OVF_LISTS = 256;  // the deferred entries go to OVF_LISTS lists (workgroup bx appends to list bx % OVF_LISTS): one hot counter would serialise the atomics
+constexpr int PAD_GRID_Y = 4;    // workgroups of PadOnlyBlockKernel per list (grid-stride over its entries)
 struct alignas(16) uint4_t { u32 x, y, z, w; };
 
 MS_HD u32 rotr32(u32 x, int n) {
@@ -187,33 +190,36 @@ template <int NWORDS, int NT> struct ShaStream {
     const u32 l4 = nbytes >= 4 ? w : ((acc << (8 * nbytes)) | (w >> (32 - 8 * nbytes)));
     append_words<1>(W, nbytes, l4);
   }
-  // compress every complete block.  With `final` (uniform over the workgroup; the caller has appended the 0x80
-  // byte of a msg_bytes-byte message) the FIPS 180-4 padding is applied on the fly: words past the 0x80 byte
-  // read as zero and the last block carries the bit length.  A second padding block has no message bytes, so
-  // every block is read from buf[0..16).
-  MS_HD void drain(bool final, u32 msg_bytes) {
+  // compress the complete block, if there is one (appends between drains are < 64 bytes: at most one).  With `final`
+  // (uniform over the workgroup; the caller has appended the 0x80 byte of a msg_bytes-byte message) the FIPS 180-4
+  // padding is applied on the fly: words past the 0x80 byte read as zero and the last block carries the bit length.
+  // When the length does not fit behind the message, the message ends with one more block that holds NO message
+  // bytes (zeros + length).  Few lanes of a wave need it (0.9 % of the Fibonacci LDE rows), so it is not compressed
+  // here: drain returns true and the caller hands the state to PadOnlyBlockKernel, which runs those lanes compacted.
+  MS_HD bool drain(bool final, u32 msg_bytes) {
     u32 limit = total >> 2, valid_end = 0;
     if (final) { valid_end = (total + 3) >> 2; limit = ((msg_bytes + 9 + 63) >> 6) << 4; }
-    const u32 done0 = done;
-    while (limit - done >= 16) {
+    const u32 pending = limit - done;
+    if (pending >= 16) {
       u32 w[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) w[i] = buf[i * NT];
       if (final) {
 #pragma unroll
         for (int i = 0; i < 16; i++) w[i] = (done + i < valid_end) ? w[i] : 0u;
-        if (limit - done == 16) { w[14] = 0; w[15] = msg_bytes * 8u; }  // messages are far below 2^29 bytes
+        if (pending == 16) { w[14] = 0; w[15] = msg_bytes * 8u; }  // messages are far below 2^29 bytes
       }
       h.compress(w);
       done += 16;
-    }
-    if (!final && done != done0) {  // one block went (appends between drains are < 64 bytes): move the leftover down
-      u32 t[NWORDS - 16];
+      if (!final) {  // move the leftover down
+        u32 t[NWORDS - 16];
 #pragma unroll
-      for (int k = 0; k < NWORDS - 16; k++) t[k] = buf[(k + 16) * NT];
+        for (int k = 0; k < NWORDS - 16; k++) t[k] = buf[(k + 16) * NT];
 #pragma unroll
-      for (int k = 0; k < NWORDS - 16; k++) buf[k * NT] = t[k];
+        for (int k = 0; k < NWORDS - 16; k++) buf[k * NT] = t[k];
+      }
     }
+    return final && pending == 32;
   }
 };
 
@@ -338,6 +344,7 @@ template <class F, int E> struct LeafHashKernel {
     u32 width, lpn; int zero_as_empty;
     size_t ngroups;
     u32* nodes;  // 8 words per digest, standard byte order in memory
+    u32* ovf_count; u32* ovf; u32 ovf_cap;  // deferred pad-only blocks: OVF_LISTS counters, and lists of ovf_cap entries of OVF_WORDS words (group, message bits)
   };
   static constexpr int MAX_BYTES = F::MAX_DIGITS + Affix<E>::MAX_BYTES;  // appended between two drains
   static constexpr int NWORDS = 16 + (3 + MAX_BYTES + 3) / 4 + 2;
@@ -352,6 +359,7 @@ template <class F, int E> struct LeafHashKernel {
     size_t row = f / p.width; u32 col = (u32)(f - row * p.width);
     const u32 nlimbs = p.lpn * (u32)E;
     u32 msg_bytes = 0;
+    bool deferred = false;
     for (u32 j = 0; j <= nlimbs; j++) {
       if (j < nlimbs) {
         const u32 k = j & (u32)(E - 1);
@@ -364,13 +372,50 @@ template <class F, int E> struct LeafHashKernel {
         msg_bytes = s.total;
         s.append_small(0x80000000u, 1);
       }
-      s.drain(j == nlimbs, msg_bytes);  // the only compression site
+      deferred = s.drain(j == nlimbs, msg_bytes);  // the only compression site
+    }
+    const u32 list = (u32)bx % (u32)OVF_LISTS;
+    const u32 slot = msrt::wave_alloc_slot(p.ovf_count + list, deferred);
+    if (deferred) {
+      u32* e = p.ovf + ((size_t)list * p.ovf_cap + slot) * OVF_WORDS;
+      e[0] = (u32)g; e[1] = msg_bytes * 8u;
+      u32* st = p.nodes + g * 8;  // the state is parked in the digest slot
+#pragma unroll
+      for (int i = 0; i < 8; i++) st[i] = s.h.st[i];
+      return;
     }
     uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + g * 8);
     uint4_t o0, o1;
     o0.x = bswap32(s.h.st[0]); o0.y = bswap32(s.h.st[1]); o0.z = bswap32(s.h.st[2]); o0.w = bswap32(s.h.st[3]);
     o1.x = bswap32(s.h.st[4]); o1.y = bswap32(s.h.st[5]); o1.z = bswap32(s.h.st[6]); o1.w = bswap32(s.h.st[7]);
     out[0] = o0; out[1] = o1;
+  }
+};
+// The last block of the messages LeafHashKernel deferred: zeros + bit length, one compacted lane per entry.
+struct PadOnlyBlockKernel {
+  static constexpr int THREADS = msmerkle::THREADS;
+  struct Params { const u32* ovf_count; const u32* ovf; u32 ovf_cap; u32* nodes; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int bx, int by, int tid, int nthreads, unsigned char*) {
+    const u32 n = p.ovf_count[bx];   // list bx
+    const u32 stride = (u32)nthreads * PAD_GRID_Y;
+    for (u32 t = (u32)by * nthreads + tid; t < n; t += stride) {
+      const u32* e = p.ovf + ((size_t)bx * p.ovf_cap + t) * OVF_WORDS;
+      Sha256 h;
+      const u32* st = p.nodes + (size_t)e[0] * 8;
+#pragma unroll
+      for (int i = 0; i < 8; i++) h.st[i] = st[i];
+      u32 w[16];
+#pragma unroll
+      for (int i = 0; i < 15; i++) w[i] = 0;
+      w[15] = e[1];
+      h.compress(w);
+      uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + (size_t)e[0] * 8);
+      uint4_t o0, o1;
+      o0.x = bswap32(h.st[0]); o0.y = bswap32(h.st[1]); o0.z = bswap32(h.st[2]); o0.w = bswap32(h.st[3]);
+      o1.x = bswap32(h.st[4]); o1.y = bswap32(h.st[5]); o1.z = bswap32(h.st[6]); o1.w = bswap32(h.st[7]);
+      out[0] = o0; out[1] = o1;
+    }
   }
 };
 

@@ -378,16 +378,32 @@ template <class F> struct Ctx : CtxBase {
     ts->nodes = total; ts->local_nodes = total; ts->Mloc = 0; ts->sharded = false;
     return 0;
   }
+  // leaf-group digests of `ngroups` groups into `out`: LeafHashKernel + the compacted pad-only blocks it deferred
+  template <int EL>
+  int leaf_hash(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, size_t lpn, size_t ngroups, u32* out) {
+    if (ngroups >> 32) return fail(MS_ERR_SHAPE, "more than 2^32 leaf groups");
+    // deferred pad-only blocks: OVF_LISTS lists, list l fed by the workgroups bx = l (mod OVF_LISTS); capacity = all their threads
+    const size_t nwg = grid1(ngroups, msmerkle::THREADS), lists = msmerkle::OVF_LISTS;
+    const size_t cap = ((nwg + lists - 1) / lists) * msmerkle::THREADS;
+    if (d_ovf.ensure(lists * 4 + lists * cap * msmerkle::OVF_WORDS * 4)) return fail(MS_ERR_NOMEM, "deferred-block lists");
+    CK(msrt::memset_dev(d_ovf.p, 0, lists * 4, stream));
+    typename msmerkle::LeafHashKernel<F, EL>::Params lp;
+    lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
+    lp.width = width; lp.lpn = (u32)lpn; lp.zero_as_empty = zae; lp.ngroups = ngroups; lp.nodes = out;
+    lp.ovf_count = d_ovf.as<u32>(); lp.ovf = d_ovf.as<u32>() + lists; lp.ovf_cap = (u32)cap;
+    next_bytes = (double)ngroups * (lpn * EL * sizeof(T) + 32);
+    CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
+    msmerkle::PadOnlyBlockKernel::Params pp{lp.ovf_count, lp.ovf, (u32)cap, out};
+    const size_t used = nwg < lists ? nwg : lists, per_list = grid1(cap, msmerkle::THREADS);
+    CK(run<msmerkle::PadOnlyBlockKernel>(K_LEAF_HASH, (unsigned)used, (unsigned)(per_list < (size_t)msmerkle::PAD_GRID_Y ? per_list : (size_t)msmerkle::PAD_GRID_Y), msmerkle::THREADS, 0, pp));
+    return 0;
+  }
   template <int EL>
   int tree_build(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, const TreeShape& ts, DevBuf& nodes) {
     if (nodes.ensure(ts.nodes * 32)) return fail(MS_ERR_NOMEM, "merkle nodes");
-    typename msmerkle::LeafHashKernel<F, EL>::Params lp;
-    lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
-    lp.width = width; lp.lpn = (u32)ts.lpn; lp.zero_as_empty = zae; lp.ngroups = ts.leaf_num / ts.lpn; lp.nodes = nodes.as<u32>();
-    const size_t blocks = (lp.ngroups + msmerkle::THREADS - 1) / msmerkle::THREADS;
-    next_bytes = (double)lp.ngroups * (ts.lpn * EL * sizeof(T) + 32);
-    CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, (unsigned)blocks, 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
-    RQ(inner_levels(nodes.as<u32>(), lp.ngroups, ts.ic));
+    const size_t ngroups = ts.leaf_num / ts.lpn;
+    RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, ngroups, nodes.as<u32>())));
+    RQ(inner_levels(nodes.as<u32>(), ngroups, ts.ic));
     return 0;
   }
   // inner levels above `nchildren` digests at nodes[0..): level-major, root last (merkle.rs:131-140)
@@ -422,11 +438,7 @@ template <class F> struct Ctx : CtxBase {
     if (Mloc * 32 > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small for the sharded commitment (need 32 * leaf groups / world bytes)");
     const size_t sub_nodes = 2 * Mloc - 1, top_nodes = 2 * W - 1;
     if (nodes.ensure((sub_nodes + top_nodes) * 32)) return fail(MS_ERR_NOMEM, "merkle nodes");
-    typename msmerkle::LeafHashKernel<F, EL>::Params lp;
-    lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
-    lp.width = width; lp.lpn = (u32)ts.lpn; lp.zero_as_empty = zae; lp.ngroups = Mloc; lp.nodes = reinterpret_cast<u32*>(xs);
-    next_bytes = (double)lp.ngroups * (ts.lpn * EL * sizeof(T) + 32);
-    CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, grid1(Mloc, msmerkle::THREADS), 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
+    RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, reinterpret_cast<u32*>(xs))));
     RQ(exchange(MS_XCHG_ALL_TO_ALL, per * 32));
     msmerkle::InterleaveDigestsKernel::Params ik{reinterpret_cast<const msmerkle::uint4_t*>(xr), reinterpret_cast<msmerkle::uint4_t*>(nodes.p), per, (u32)W};
     CK(run<msmerkle::InterleaveDigestsKernel>(K_IO, grid1(Mloc * 2, msmerkle::InterleaveDigestsKernel::THREADS), 1, msmerkle::InterleaveDigestsKernel::THREADS, 0, ik));
@@ -459,7 +471,7 @@ template <class F> struct Ctx : CtxBase {
   struct Round { DevBuf poly, cw, nodes; size_t cap = 0, ncoef = 0, D = 0; TreeShape ts; size_t m = 0; /* sharded: local codeword = limbs x 2 cosets x m */ };
   std::vector<Round*> rounds; size_t nrounds_done = 0, fri_rounds = 0, fri_blowup = 0;
   bool have_deep = false; XE cur_z; XE cur_B[2];
-  DevBuf d_folded, d_sh, d_blob, d_tabs, d_targets, d_idx, d_deg;
+  DevBuf d_folded, d_sh, d_blob, d_tabs, d_targets, d_idx, d_deg, d_ovf;
   size_t blob_size = 0;
 
   int ensure_polys(size_t count) {
@@ -496,7 +508,7 @@ template <class F> struct Ctx : CtxBase {
   ~Ctx() {
     for (auto& kv : plans) { kv.second->tw_lo.release(); kv.second->tw_hi.release(); kv.second->vtw.release(); kv.second->w0.release(); for (auto& b : kv.second->w_r) b.release(); delete kv.second; }
     for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
-    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg};
+    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf};
     for (DevBuf* b : bufs) b->release();
     if (pinned) msrt::free_host(pinned);
     if (own_stream) msrt::stream_destroy(own_stream);

@@ -49,6 +49,9 @@ inline int launch(Stream*, unsigned gx, unsigned gy, int threads, size_t lds_byt
 }
 MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { if (v < *a) *a = v; }
 MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { if (v > *a) *a = v; }
+MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { unsigned o = *a; *a = o + v; return o; }
+// one slot of a device list per lane that wants one (call from all live lanes)
+MS_DEV unsigned wave_alloc_slot(unsigned* counter, bool want) { if (!want) return 0; unsigned o = *counter; *counter = o + 1; return o; }
 }  // namespace msrt
 MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 
@@ -102,6 +105,18 @@ inline int launch(Stream* s, unsigned gx, unsigned gy, int threads, size_t lds_b
 }
 MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { atomicMin(a, v); }
 MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { atomicMax(a, v); }
+MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { return atomicAdd(a, v); }
+// one slot of a device list per lane that wants one (call from all live lanes): ONE atomic per wave, not per lane
+MS_DEV unsigned wave_alloc_slot(unsigned* counter, bool want) {
+  const unsigned long long mask = __ballot(want);
+  if (!want) return 0;
+  const unsigned lane = __lane_id();
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned base = 0;
+  if ((int)lane == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
+  base = (unsigned)__shfl((int)base, leader);
+  return base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+}
 }  // namespace msrt
 MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
