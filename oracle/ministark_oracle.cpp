@@ -405,22 +405,28 @@ template <class F> struct NttPlan {
   }
 };
 template <class F> static void ntt_inplace(const NttPlan<F>& pl, u64* a, size_t stride) {
-  size_t n = pl.n;
-  int lg = ctz64(n);
+  const size_t n = pl.n;
+  const int lg = ctz64(n);
+  // the OpenMP clauses only take effect for the all-cores baseline of large single transforms (or_set_threads > 1 and not
+  // already inside the per-column parallel loop: nested regions run on one thread)
+  const bool par = g_threads > 1 && n >= 8192;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (par)
   for (size_t i = 0; i < n; i++) {
     size_t j = 0;
     for (int b = 0; b < lg; b++) j |= ((i >> b) & 1) << (lg - 1 - b);
     if (i < j) { u64 t = a[i * stride]; a[i * stride] = a[j * stride]; a[j * stride] = t; }
   }
   for (size_t len = 2; len <= n; len <<= 1) {
-    size_t half = len >> 1, step = n / len;
-    for (size_t i = 0; i < n; i += len)
-      for (size_t j = 0; j < half; j++) {
-        u64 u = a[(i + j) * stride];
-        u64 v = F::mul(a[(i + j + half) * stride], pl.tw[j * step]);
-        a[(i + j) * stride] = F::add(u, v);
-        a[(i + j + half) * stride] = F::sub(u, v);
-      }
+    const size_t half = len >> 1, step = n / len;
+    // n/2 independent butterflies per stage, indexed b = (block, j)
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (par)
+    for (size_t b = 0; b < n / 2; b++) {
+      const size_t j = b & (half - 1), i = (b - j) * 2;
+      u64 u = a[(i + j) * stride];
+      u64 v = F::mul(a[(i + j + half) * stride], pl.tw[j * step]);
+      a[(i + j) * stride] = F::add(u, v);
+      a[(i + j + half) * stride] = F::sub(u, v);
+    }
   }
 }
 
@@ -871,7 +877,14 @@ static int fri_verify(int zae, size_t rounds, size_t nq, const u64* betas_in, co
 
 extern "C" {
 
-void or_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+void or_set_threads(int n) {
+  g_threads = n < 1 ? 1 : n;
+  if (g_threads > 1) {  // create the thread team now: its first use costs ~1 s in a process that already hosts another OpenMP runtime
+    volatile int sink = 0;
+#pragma omp parallel num_threads(g_threads)
+    { sink = sink + 0; }
+  }
+}
 int or_max_threads() {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -122,6 +122,34 @@ def drive(sess, field, trace, blowup, nq_fri, seed, rounds=None, q_ood=2, read_b
     return out
 
 
+def case_merkle_length_sweep(mk, field, lpn=6, ext=1):
+    """Leaf groups whose decimal strings sweep every message length around the SHA-256 block boundaries (55/56, 119/120, ...):
+    exercises the kernels' on-the-fly padding and the deferred pad-only block."""
+    ctx = mk(field)
+    p = MODULUS[field]
+    maxd = len(str(p - 1))
+    groups = 256
+    leafs = np.zeros(groups * lpn * ext, dtype=np.uint64)
+    per = lpn * ext
+    for g in range(groups):
+        total = per + (g * 7) % (per * (maxd - 1) + 1)      # total digits of the group, from all-1-digit to all-max-digit
+        digs = [1] * per
+        left = total - per
+        k = 0
+        while left > 0:
+            add = min(maxd - 1, left)
+            digs[k % per] += add
+            left -= add
+            k += 1
+        for j, d in enumerate(digs):
+            v = 10 ** (d - 1) + (g * 31 + j) % 9
+            leafs[g * per + j] = v if v < p else p - 1 - j
+    rc, nodes, root = ctx.merkle_commit(leafs, ext, lpn, 2)
+    orc_rc, onodes, oroot = orc.merkle_build(leafs, ext, lpn, 2)
+    assert rc == 0 and orc_rc == 0, ctx.last_error()
+    assert (nodes == onodes).all() and root == oroot
+
+
 def case_prove(mk, field, log_n, blowup, nq_fri=2, seed=77, read_big=True, steps=None):
     N = 1 << log_n
     if steps is None:

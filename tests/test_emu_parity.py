@@ -53,6 +53,11 @@ def test_merkle(mk, field, leaf_num, ext, lpn, ic):
     pc.case_merkle(mk, field, leaf_num, e, lpn, ic, special=True)
 
 
+@pytest.mark.parametrize("field,lpn,ext", [(0, 6, 1), (0, 3, 1), (0, 2, 2), (0, 16, 1), (1, 6, 1), (1, 12, 1), (1, 2, 4), (1, 4, 4)])
+def test_merkle_message_length_sweep(mk, field, lpn, ext):
+    pc.case_merkle_length_sweep(mk, field, lpn, ext)
+
+
 @pytest.mark.parametrize("field,log_n,blowup", [(0, 4, 2), (0, 3, 8), (0, 6, 8), (1, 3, 2), (1, 5, 4), (0, 10, 8), (1, 10, 8)])
 def test_prove(mk, field, log_n, blowup):
     pc.case_prove(mk, field, log_n, blowup)
