@@ -185,15 +185,19 @@ def main():
                                              f"scaled linearly x{int(scale)} to 2^{args.log_rows} rows (optimistic for the CPU: ignores the log factor)"}
             # the same sample with OpenMP over the oracle's independent loops (columns, leaf groups, tree levels):
             # what a rayon-enabled reference could reach on this host; the reference itself is single-threaded (README.md:33)
-            nthr = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0))))
-            if nthr > 1:
+            ncpu = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0))))
+            best = None
+            for nthr in sorted({t for t in (16, 32, 64, ncpu) if 1 < t <= ncpu}):  # the port's fork-join loops stop scaling well before 128 threads: keep the best
                 orc.set_threads(nthr)
                 c0 = time.perf_counter()
                 pc.drive(orc.Session(args.field), args.field, tr, args.blowup, max(0, cfg.fri_queries - 2), seed=1, q_ood=cfg.constrain_queries, read_big=False)
                 ctm = time.perf_counter() - c0
-                orc.set_threads(1)
-                out["cpu_baseline"]["all_cores"] = {"value": 1.0 / (ctm * scale), "unit": "proofs/s", "cores": nthr, "kind": "port",
-                                                    "sample": f"same 2^{cl}-row proof with OpenMP x{nthr} took {ctm:.2f} s"}
+                if best is None or ctm < best[0]:
+                    best = (ctm, nthr)
+            orc.set_threads(1)
+            if best is not None:
+                out["cpu_baseline"]["all_cores"] = {"value": 1.0 / (best[0] * scale), "unit": "proofs/s", "cores": best[1], "kind": "port", "host_cpus": ncpu,
+                                                    "sample": f"same 2^{cl}-row proof with OpenMP x{best[1]} (best of 16/32/64/{ncpu} threads) took {best[0]:.2f} s"}
         print(json.dumps(out), flush=True)
     grp.close()
 
