@@ -57,6 +57,9 @@ struct GL {
   }
   static MS_HD T from_u64(u64 v) { return v; }
   static MS_HD u64 to_u64(T v) { return v; }
+  // twiddle tables hold to_tw(w); mul_tw(a, to_tw(w)) == a * w.  Nothing to gain for Goldilocks: identity.
+  static MS_HD T to_tw(T w) { return w; }
+  static MS_HD T mul_tw(T a, T w_tab) { return mul(a, w_tab); }
 };
 
 struct BB {
@@ -83,6 +86,10 @@ struct BB {
   static MS_HD T mul(T a, T b) { return redc((u64)redc((u64)a * (u64)b) * (u64)R2); }
   static MS_HD T from_u64(u64 v) { return (T)v; }
   static MS_HD u64 to_u64(T v) { return v; }
+  // twiddle tables hold the Montgomery form w * 2^32 mod p: a canonical value times a table entry is ONE product and ONE
+  // reduction (a * wR / R = a * w), and the product of two table entries is again in table form
+  static MS_HD T to_tw(T w) { return (T)((((u64)w) << 32) % P); }
+  static MS_HD T mul_tw(T a, T w_tab) { return redc((u64)a * (u64)w_tab); }
 };
 
 template <class F> MS_HD typename F::T f_pow(typename F::T a, u64 e) {

@@ -230,10 +230,10 @@ template <class F> struct Ctx : CtxBase {
     const size_t nlo = (size_t)1 << pl->lo_bits, nhi = (size_t)1 << (log_n - pl->lo_bits);
     std::vector<T> lo(nlo), hi(nhi);
     T x = F::from_u64(1);
-    for (size_t j = 0; j < nlo; j++) { lo[j] = x; x = F::mul(x, wn); }
+    for (size_t j = 0; j < nlo; j++) { lo[j] = F::to_tw(x); x = F::mul(x, wn); }
     T wh = x;  // w^nlo
     x = F::from_u64(1);
-    for (size_t j = 0; j < nhi; j++) { hi[j] = x; x = F::mul(x, wh); }
+    for (size_t j = 0; j < nhi; j++) { hi[j] = F::to_tw(x); x = F::mul(x, wh); }
     if (pl->tw_lo.ensure(nlo * sizeof(T)) || pl->tw_hi.ensure(nhi * sizeof(T))) { delete pl; return fail(MS_ERR_NOMEM, "twiddle tables"); }
     CK(msrt::h2d(pl->tw_lo.p, lo.data(), nlo * sizeof(T), stream));
     CK(msrt::h2d(pl->tw_hi.p, hi.data(), nhi * sizeof(T), stream));
@@ -244,7 +244,7 @@ template <class F> struct Ctx : CtxBase {
       if (inverse) wr = f_inv<F>(wr);
       std::vector<T> tab(r);
       x = F::from_u64(1);
-      for (size_t j = 0; j < r; j++) { tab[j] = x; x = F::mul(x, wr); }
+      for (size_t j = 0; j < r; j++) { tab[j] = F::to_tw(x); x = F::mul(x, wr); }
       if (pl->w_r[i].ensure(r * sizeof(T))) { delete pl; return fail(MS_ERR_NOMEM, "w_r table"); }
       CK(msrt::h2d(pl->w_r[i].p, tab.data(), r * sizeof(T), stream));
       CK(msrt::sync(stream));
@@ -255,7 +255,7 @@ template <class F> struct Ctx : CtxBase {
       if (inverse) wv = f_inv<F>(wv);
       std::vector<T> tab(cnt);
       x = F::from_u64(1);
-      for (size_t j = 0; j < cnt; j++) { tab[j] = x; x = F::mul(x, wv); }
+      for (size_t j = 0; j < cnt; j++) { tab[j] = F::to_tw(x); x = F::mul(x, wv); }
       if (pl->w0.ensure(cnt * sizeof(T))) { delete pl; return fail(MS_ERR_NOMEM, "w0 table"); }
       CK(msrt::h2d(pl->w0.p, tab.data(), cnt * sizeof(T), stream));
       CK(msrt::sync(stream));
@@ -267,7 +267,7 @@ template <class F> struct Ctx : CtxBase {
       if (inverse) wv = f_inv<F>(wv);
       std::vector<T> tab(cnt);
       x = F::from_u64(1);
-      for (size_t j = 0; j < cnt; j++) { tab[j] = x; x = F::mul(x, wv); }
+      for (size_t j = 0; j < cnt; j++) { tab[j] = F::to_tw(x); x = F::mul(x, wv); }
       if (pl->vtw.ensure(cnt * sizeof(T))) { delete pl; return fail(MS_ERR_NOMEM, "vtw table"); }
       CK(msrt::h2d(pl->vtw.p, tab.data(), cnt * sizeof(T), stream));
       CK(msrt::sync(stream));
@@ -345,7 +345,8 @@ template <class F> struct Ctx : CtxBase {
       pp.n_in = (k == 0) ? n_in : n;
       pp.tw_lo = pl->tw_lo.template as<T>(); pp.tw_hi = pl->tw_hi.template as<T>(); pp.w_r = pl->w_r[k].template as<T>();
       pp.vtw = pl->vtw.template as<T>(); pp.w0 = pl->w0.template as<T>();
-      pp.scale = (inverse && k == P - 1) ? pl->n_inv : F::from_u64(1);
+      pp.do_scale = (inverse && k == P - 1) ? 1 : 0;
+      pp.scale = F::to_tw(pp.do_scale ? pl->n_inv : F::from_u64(1));
       pp.log_n = log_n; pp.log_r = pl->K[k]; pp.log_Rp = log_Rp; pp.lo_bits = pl->lo_bits;
       pp.log_r0 = (k == 0) ? log_r0 : 0; pp.log_rho = (k == 0) ? pl->log_rho : 0;
       const int cols_log = log_n - pl->K[k];

@@ -59,11 +59,12 @@ template <class F> struct PassParams {
   const T* src; T* dst;
   size_t src_bstride, dst_bstride;  // elements between consecutive batch entries (blockIdx.y)
   size_t n_in;                      // valid input elements (zero padded); first real pass only
+  // every table holds F::to_tw(w) (Goldilocks: w itself; BabyBear: Montgomery form, one reduction per twiddle multiply)
   const T* tw_lo; const T* tw_hi;   // w_n^j = tw_lo[j & lo_mask] * tw_hi[j >> lo_bits]
   const T* w_r;                     // w_r^j, j < r
   const T* vtw;                     // virtual pass: w_(r0*r)^j, j < r0*r
   const T* w0;                      // virtual pass: w_(r0)^j, j < r0
-  T scale;                          // multiplied into the output of the last pass (1 = none)
+  T scale; u32 do_scale;            // table form of the factor multiplied into the output of the last pass (do_scale = 0: none)
   u32 log_n, log_r, log_Rp, log_C, lo_bits;
   u32 log_r0 /* >0: this pass loads through a virtual r0-point pass */, log_rho /* of whose inputs 2^log_rho blocks are non-zero */;
   u32 last;
@@ -95,7 +96,7 @@ template <bool INV, int LOG2H2, int J> struct TwMul<GL, INV, LOG2H2, J> {
   }
 };
 template <bool INV, int LOG2H2, int J> struct TwMul<BB, INV, LOG2H2, J> {
-  static MS_HD u32 diff_mul(u32 a, u32 b, const u32* w_r, int log_r) { return BB::mul(BB::sub(a, b), w_r[(size_t)J << (log_r - LOG2H2)]); }
+  static MS_HD u32 diff_mul(u32 a, u32 b, const u32* w_r, int log_r) { return BB::mul_tw(BB::sub(a, b), w_r[(size_t)J << (log_r - LOG2H2)]); }
 };
 
 template <class F, bool INV, int B, int S, int BLK, int J> struct DifStage {
@@ -173,7 +174,7 @@ template <class F, bool INV, int TH> struct PassKernel {
 #pragma unroll
       for (int e = 0; e < (1 << B); e++) {
         T v = x[bitrev(e, B)];
-        if (e != 0 && lo != 0) v = F::mul(v, w[((size_t)(e * lo)) << (K - s_lo - B)]);
+        if (e != 0 && lo != 0) v = F::mul_tw(v, w[((size_t)(e * lo)) << (K - s_lo - B)]);
         tile[tix(row0 + e * q, cidx, lc)] = v;
       }
     }
@@ -182,7 +183,7 @@ template <class F, bool INV, int TH> struct PassKernel {
   static MS_DEV T tw_global(const Params& p, size_t e) {
     T tw = p.tw_lo[e & (((size_t)1 << p.lo_bits) - 1)];
     const size_t eh = e >> p.lo_bits;
-    if (eh) tw = F::mul(tw, p.tw_hi[eh]);
+    if (eh) tw = F::mul_tw(tw, p.tw_hi[eh]);
     return tw;
   }
 
@@ -219,10 +220,10 @@ template <class F, bool INV, int TH> struct PassKernel {
             const size_t kk = k + blk * (size_t)k1;
             T x = (kk < p.n_in) ? src[kk] : (T)0;
             const int e = (i1 * k1) & r0m;
-            if (e) x = F::mul(x, p.w0[e]);
+            if (e) x = F::mul_tw(x, p.w0[e]);
             v = F::add(v, x);
           }
-          if (i1) v = F::mul(v, p.vtw[(size_t)i1 * row]);
+          if (i1) v = F::mul_tw(v, p.vtw[(size_t)i1 * row]);
           tile[tix(row, cidx, lc)] = v;
         }
       }
@@ -245,7 +246,7 @@ template <class F, bool INV, int TH> struct PassKernel {
     }
     // store phase
     T* dst = p.dst + (size_t)by * p.dst_bstride;
-    const bool do_scale = p.scale != F::from_u64(1);
+    const bool do_scale = p.do_scale != 0;
     const int Rp_m = (1 << p.log_Rp) - 1;
     for (int idx = tid; idx < r * C; idx += TH) {
       int row, cidx, inew, kk, i_done;
@@ -262,9 +263,9 @@ template <class F, bool INV, int TH> struct PassKernel {
       const size_t k_low = (f0 + cidx) >> p.log_Rp;
       if (!p.last && k_low) {  // w_n^(k_low * (output index so far)); the i_done term belongs to the virtual pass
         const size_t e = k_low * (((size_t)inew << p.log_Rp) + (p.log_r0 ? (size_t)i_done : 0));
-        if (e) v = F::mul(v, tw_global(p, e));
+        if (e) v = F::mul_tw(v, tw_global(p, e));
       }
-      if (do_scale) v = F::mul(v, p.scale);
+      if (do_scale) v = F::mul_tw(v, p.scale);
       const size_t out = ((k_low << p.log_Rp) << K) + ((size_t)(f0 + cidx) & (size_t)Rp_m) + ((size_t)inew << p.log_Rp);
       dst[out] = v;
     }
@@ -298,7 +299,7 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
   static MS_DEV T tw_global(const Params& p, size_t e) {
     T tw = p.tw_lo[e & (((size_t)1 << p.lo_bits) - 1)];
     const size_t eh = e >> p.lo_bits;
-    if (eh) tw = F::mul(tw, p.tw_hi[eh]);
+    if (eh) tw = F::mul_tw(tw, p.tw_hi[eh]);
     return tw;
   }
   // row bits of a sub-round work item g: B zero bits inserted at position SLO
@@ -326,7 +327,7 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
 #pragma unroll
         for (int e = 0; e < (1 << B); e++) {
           T v = x[bitrev(e, B)];
-          if (e != 0) v = F::mul(v, w[e * a + ((e * LO_J) << SH)]);  // w_{Q 2^B}^(e*lo); lo == 0 multiplies by w[0] = 1
+          if (e != 0) v = F::mul_tw(v, w[e * a + ((e * LO_J) << SH)]);  // w_{Q 2^B}^(e*lo); lo == 0 multiplies by w[0] = 1
           base[(ROW_J + e * Q) * CP] = v;
         }
       }
@@ -340,8 +341,8 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
   }
   template <int IT> static MS_DEV void store_rows(const Params& p, const T* trow, T* out, const T* twr, bool tw, bool do_scale) {
     T v = trow[IT * RPT * CP];
-    if (tw) v = F::mul(v, twr[IT * RPT]);   // one twiddle per tile ROW, shared by its 16 columns
-    if (do_scale) v = F::mul(v, p.scale);
+    if (tw) v = F::mul_tw(v, twr[IT * RPT]);   // one twiddle per tile ROW, shared by its 16 columns
+    if (do_scale) v = F::mul_tw(v, p.scale);
     out[(size_t)row_to_inew(IT * RPT, K) << p.log_Rp] = v;
     if constexpr (IT + 1 < NIT) store_rows<IT + 1>(p, trow, out, twr, tw, do_scale);
   }
@@ -376,7 +377,7 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
       return;
     }
     T* dst = p.dst + (size_t)by * p.dst_bstride;
-    const bool do_scale = p.scale != F::from_u64(1);
+    const bool do_scale = p.do_scale != 0;
     if (p.log_Rp) {
       // columns stay columns: out = k_low*Rp*r + i_done + Rp*i_new, C-element runs
       const size_t f = f0 + cidx, k_low = f0 >> p.log_Rp, i_done = f & (((size_t)1 << p.log_Rp) - 1);
@@ -390,8 +391,8 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
         const int inew = idx & (R - 1), c2 = idx >> K;
         const size_t f = f0 + c2;
         T v = tile[inew_to_row(inew, K) * CP + c2];
-        if (!p.last) { const size_t e = (size_t)inew * f; if (e) v = F::mul(v, tw_global(p, e)); }
-        if (do_scale) v = F::mul(v, p.scale);
+        if (!p.last) { const size_t e = (size_t)inew * f; if (e) v = F::mul_tw(v, tw_global(p, e)); }
+        if (do_scale) v = F::mul_tw(v, p.scale);
         dst[(f << K) + inew] = v;
       }
     }
