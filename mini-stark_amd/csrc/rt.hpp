@@ -11,7 +11,14 @@
 #include <cstdint>
 #include <cstring>
 
-#if defined(MS_EMU)
+#if defined(MS_HOST_ONLY)
+// host code that only needs the field arithmetic of field.hpp (the CPU verifier of mini-stark_amd/host/stark_host.cpp)
+#define MS_HD inline
+#define MS_DEV inline
+#define MS_RESTRICT
+MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+
+#elif defined(MS_EMU)
 #include <cstdlib>
 #include <vector>
 #define MS_HD inline

@@ -42,7 +42,7 @@ def _host():
 
 
 class HostStark:
-    """StarkConfig::new + Stark::new + Stark::prove (src/starks.rs:268-310, 40-57, 59-169) in C++."""
+    """StarkConfig::new + Stark::new + Stark::prove + Stark::verify (src/starks.rs:268-310, 40-57, 59-169, 171-235) in C++."""
 
     def __init__(self, ctx: Context, security_bits: int, blowup_factor: int, steps: int, trace_columns: int):
         self.H, self.ctx = _host(), ctx
@@ -99,6 +99,41 @@ class HostStark:
         blob = self._bytes(self.H.msh_proof_fri_blob) if read_fri_proof else b""
         return StarkProof(self._bytes(self.H.msh_proof_arthur), bytes(tc), bytes(lc), ev[:, :c, :], ev[:, c, :],
                           FriProof(blob, device_resident=not read_fri_proof), [roots[i:i + 32] for i in range(0, len(roots), 32)])
+
+    def derive_constrains(self, trace):
+        """TraceTable::derive_constrains (src/air.rs:127-144) for the verifier's copy of the AIR: the c constraint polynomials
+        in coefficient form, [c][N] canonical u64 (computed on the GPU: INTT of the trace columns + the transition closures)."""
+        ctx = self.ctx
+        rc, _ = ctx.trace_commit(trace.data, trace.constrain_number())
+        ctx.check(rc)
+        ctx.check(ctx.interpolate())
+        for sc, idx in trace.transitions:
+            ctx.check(ctx.polys_lincomb(sc, idx))
+        return np.stack([ctx.poly_read(i) for i in range(ctx.polys_count())])
+
+    def verify(self, constrains, proof: StarkProof, zero_display_empty=True) -> bool:
+        """Stark::verify (src/starks.rs:171-235, with Fri::verify src/fri.rs:191-290 and MerkleRoot::check_proof
+        src/merkle.rs:312-338) on the CPU, as in the reference.  Returns True/False; the reason of a rejection is in
+        `self.last_verify_error`.  Raises MsError on malformed input."""
+        cs = np.ascontiguousarray(constrains, dtype=np.uint64)
+        c, N = cs.shape
+        ev = np.ascontiguousarray(np.concatenate([np.asarray(proof.constrain_queries, dtype=np.uint64).reshape(-1, c, self.ctx.e),
+                                                  np.asarray(proof.validity_queries, dtype=np.uint64).reshape(-1, 1, self.ctx.e)], axis=1))
+        roots = b"".join(proof.fri_roots)
+        blob = proof.fri_proof.blob
+        why = C.create_string_buffer(512)
+        u8p = C.POINTER(C.c_uint8)
+
+        def b(x):
+            return C.cast(C.create_string_buffer(bytes(x), max(1, len(x))), u8p)
+        self.H.msh_stark_verify.restype = C.c_int
+        rc = self.H.msh_stark_verify(self.h, cs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(c), C.c_size_t(N), b(proof.arthur), C.c_size_t(len(proof.arthur)),
+                                     b(proof.trace_commit), b(proof.constrain_trace_commit), ev.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(ev.size),
+                                     b(roots), C.c_size_t(len(proof.fri_roots)), b(blob), C.c_size_t(len(blob)), C.c_int(1 if zero_display_empty else 0), why, C.c_size_t(512))
+        self.last_verify_error = why.value.decode()
+        if rc < 0:
+            raise MsError(rc, self.last_verify_error)
+        return rc == 1
 
     def prove(self, trace, trace_device_ptr=None, read_fri_proof=True) -> StarkProof:
         self.ctx.check(self.prove_raw(trace, trace_device_ptr, read_fri_proof))

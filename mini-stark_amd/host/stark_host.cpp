@@ -5,22 +5,22 @@
 //   ministark::StarkConfig   <- StarkConfig::new             src/starks.rs:268-310 (+312-332)
 //   ministark::Stark::prove  <- Stark::prove                 src/starks.rs:59-169
 //                               Fri::commit_phase/query_phase src/fri.rs:64-189 (inlined: same call order)
+//   ministark::Stark::verify <- Stark::verify / Fri::verify / MerkleRoot::check_proof   src/starks.rs:171-235, src/fri.rs:191-290,
+//                               src/merkle.rs:312-338 — on the CPU, as in the reference
 //   ministark::Transcript    <- nimue Merlin                  BUILD-DEFINED stand-in: a SHA-256 hash chain with the
 //                                                             message ORDER of src/fiatshamir.rs:48-64,100-116;
 //                                                             not nimue's bytes (its source is unavailable).
-// Every field operation happens on the GPU inside libministark.so; this file only moves challenges and
-// commitments between the transcript and the stage functions.  It calls nothing but ms_* symbols, which
-// are resolved at load time from the already-loaded libministark.so.
+// Every field operation of the PROVER happens on the GPU inside libministark.so; prove() only moves challenges and
+// commitments between the transcript and the stage functions and calls nothing but ms_* symbols, which are resolved at
+// load time from the already-loaded libministark.so.  verify() is host arithmetic (csrc/field.hpp), like the reference's.
 #include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/ministark.h"
-
-typedef uint64_t u64;
-typedef uint32_t u32;
-typedef uint8_t u8;
+#define MS_HOST_ONLY 1
+#include "../csrc/field.hpp"  // Goldilocks / BabyBear arithmetic for the CPU verifier (typedefs u64, u32, u8)
 
 namespace ministark {
 
@@ -182,6 +182,157 @@ struct Stark {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Verifier (CPU).  src/starks.rs:171-235, src/fri.rs:191-290, src/merkle.rs:312-338.
+// ------------------------------------------------------------------------------------------------
+// nimue's Arthur: replays the prover's messages out of `arthur` into the same hash chain
+struct Arthur {
+  Transcript t; const u8* data; size_t len, pos = 0;
+  Arthur(const std::string& domsep, const u8* d, size_t n) : t(domsep), data(d), len(n) {}
+  bool next_bytes(u8* out, size_t n) { if (pos + n > len) return false; memcpy(out, data + pos, n); t.add_bytes(data + pos, n); pos += n; return true; }
+  bool next_scalars(u64* out, size_t n) { return next_bytes((u8*)out, n * 8); }
+};
+
+// arkworks Display (see csrc/merkle.hpp): decimal, ZERO -> "" when zae, "QuadExtField(c0 + c1 * u)" nested
+template <class F> static void display(std::string& s, const u64* c, int E, int zae) {
+  if (E == 1) { if (c[0] != 0 || !zae) s += std::to_string((unsigned long long)c[0]); return; }
+  s += "QuadExtField("; display<F>(s, c, E / 2, zae); s += " + "; display<F>(s, c + E / 2, E / 2, zae); s += " * u)";
+}
+// MerkleRoot::check_proof (merkle.rs:312-338) on a serialised MerklePath (include/ministark.h); y must be one of the leaf_neighbours
+template <class F, int E> static bool check_path(const u8 root[32], const u8* p, size_t avail, size_t* used, const u64* y, int zae, std::string* why) {
+  const size_t lpn = 2;
+  if (avail < 8 + lpn * E * 8 + 8) { *why = "truncated Merkle path"; return false; }
+  const u64* q = (const u64*)p;
+  const u64* leafs = q + 1;
+  const u64 nlev = q[1 + lpn * E];
+  const size_t total = 8 + lpn * E * 8 + 8 + (size_t)nlev * 64;
+  if (nlev > 64 || avail < total) { *why = "truncated Merkle path"; return false; }
+  *used = total;
+  bool has = false;
+  for (size_t i = 0; i < lpn; i++) { bool eq = true; for (int k = 0; k < E; k++) eq = eq && leafs[i * E + k] == y[k]; has = has || eq; }
+  if (!has) { *why = "opened value is not among the leaf_neighbours (fri.rs:236-238)"; return false; }
+  std::string msg;
+  for (size_t i = 0; i < lpn; i++) display<F>(msg, leafs + i * E, E, zae);          // calculate_from_leafs, merkle.rs:162-168
+  u8 prev[32]; { Sha256 h; h.update(msg.data(), msg.size()); h.finish(prev); }
+  const u8* lv = p + 8 + lpn * E * 8 + 8;
+  for (u64 l = 0; l < nlev; l++, lv += 64) {
+    if (memcmp(lv, prev, 32) != 0 && memcmp(lv + 32, prev, 32) != 0) { *why = "Merkle path does not contain the running digest"; return false; }
+    Sha256 h; h.update(lv, 64); h.finish(prev);                                      // calculate_from_nodes, merkle.rs:171-177
+  }
+  if (memcmp(prev, root, 32) != 0) { *why = "Merkle path does not end at the round's root"; return false; }
+  return true;
+}
+
+template <class F, int E> struct Verifier {
+  typedef typename F::T T;
+  typedef Ext<F, E> X;
+  static X load(const u64* v) { X r; for (int k = 0; k < E; k++) r.c[k] = F::from_u64(v[k]); return r; }
+  static bool canon(const u64* v, size_t n) { for (size_t i = 0; i < n; i++) if (v[i] >= F::P) return false; return true; }
+  static bool eq(const X& a, const u64* v) { for (int k = 0; k < E; k++) if (F::to_u64(a.c[k]) != v[k]) return false; return true; }
+  // base-coefficient polynomial at an extension point (field.rs:23-32 extend_poly + evaluate)
+  static X horner_base(const u64* coef, size_t n, const X& z) {
+    X acc = e_zero<F, E>();
+    for (size_t i = n; i-- > 0;) { acc = e_mul<F>(acc, z); acc.c[0] = F::add(acc.c[0], F::from_u64(coef[i])); }
+    return acc;
+  }
+  // 1 accepted, 0 rejected (reason in *why), < 0 malformed input
+  static int run(const StarkConfig& c, const u64* constrains, size_t nc, size_t N, const StarkProof& pr, int zae, std::string* why) {
+    const int e = E; const u64 p = c.p;
+    if (!canon(constrains, nc * N) || !canon(pr.evals.data(), pr.evals.size())) { *why = "non-canonical element"; return MS_ERR_ARG; }
+    // 1. commits match the transcript (starks.rs:186-193)
+    Arthur ar(c.domsep, pr.arthur.data(), pr.arthur.size());
+    u8 d[32];
+    if (!ar.next_bytes(d, 32) || memcmp(d, pr.trace_commit, 32)) { *why = "trace commit does not match the transcript"; return 0; }
+    u64 shift; ar.t.challenge_scalars(&shift, 1, p);
+    if (!ar.next_bytes(d, 32) || memcmp(d, pr.constrain_trace_commit, 32)) { *why = "constraint-trace commit does not match the transcript"; return 0; }
+    u64 r; ar.t.challenge_scalars(&r, 1, p);
+    // 2. DEEP-ALI linking (starks.rs:195-225)
+    const size_t q = c.constrain_queries;
+    if (pr.evals.size() != q * (nc + 1) * e) { *why = "wrong number of out-of-domain values"; return 0; }
+    std::vector<u64> z(q * e); ar.t.challenge_scalars(z.data(), z.size(), p);
+    // c_x = sum_i r^i f_i, then divide_by_vanishing_poly over Radix2(degree + 1): the FIRST returned polynomial must be zero and
+    // the SECOND is evaluated (starks.rs:220-224; the reference binds (quotient, remainder) to the names (rest, quotient): quirk Q1)
+    size_t nd = 1; while (nd < c.degree + 1) nd <<= 1;
+    std::vector<u64> cx(N, 0);
+    { T rp = F::from_u64(1);
+      for (size_t i = 0; i < nc; i++) { for (size_t k = 0; k < N; k++) cx[k] = F::to_u64(F::add(F::from_u64(cx[k]), F::mul(rp, F::from_u64(constrains[i * N + k])))); rp = F::mul(rp, F::from_u64(r)); } }
+    std::vector<u64> rem(nd < N ? nd : N, 0);
+    for (size_t k = 0; k < N; k++) {
+      if (k >= nd && cx[k] != 0) { *why = "mixed constraint polynomial has degree >= |trace domain|: first output of divide_by_vanishing_poly is not zero (starks.rs:221)"; return 0; }
+      if (k < rem.size()) rem[k] = cx[k];
+    }
+    for (size_t t = 0; t < q; t++) {
+      const X zz = load(&z[t * e]);
+      const u64* ev = &pr.evals[t * (nc + 1) * e];
+      for (size_t i = 0; i < nc; i++)
+        if (!eq(horner_base(constrains + i * N, N, zz), ev + i * e)) { *why = "constraint polynomial evaluation does not match the proof (starks.rs:215)"; return 0; }
+      if (!eq(horner_base(rem.data(), rem.size(), zz), ev + nc * e)) { *why = "validity evaluation does not match the proof (starks.rs:224)"; return 0; }
+    }
+    // 3. FRI (fri.rs:191-290)
+    const size_t R = c.rounds, nq = c.fri_queries;
+    if (R < 1 || pr.fri_roots.size() != R * 32) { *why = "wrong number of FRI roots"; return 0; }
+    std::vector<X> zs, alphas, B0, B1;
+    for (size_t i = 1; i < R; i++) {                                              // read_proof_transcript, fri.rs:247-279
+      std::vector<u64> v(e), b(2 * e), a(e);
+      ar.t.challenge_scalars(v.data(), e, p);
+      if (!ar.next_scalars(b.data(), 2 * e) || !canon(b.data(), 2 * e)) { *why = "transcript too short / DEEP coefficients not canonical"; return 0; }
+      ar.t.challenge_scalars(a.data(), e, p);
+      if (!ar.next_bytes(d, 32)) { *why = "transcript too short"; return 0; }
+      // round i's commitment is in the transcript; round 0's never is (fri.rs:73-82: as in the reference) and is taken from the proof
+      if (memcmp(d, pr.fri_roots.data() + i * 32, 32)) { *why = "FRI round root does not match the transcript"; return 0; }
+      zs.push_back(load(v.data())); alphas.push_back(load(a.data())); B0.push_back(load(b.data())); B1.push_back(load(b.data() + e));
+    }
+    if (ar.pos != ar.len) { *why = "trailing bytes in the transcript"; return 0; }
+    std::vector<u8> raw(8 * nq); ar.t.challenge_bytes(raw.data(), raw.size());
+    if (R > 63) { *why = "too many rounds"; return MS_ERR_ARG; }
+    const u64 dsize = (u64)1 << R;
+    const T g = f_root_of_unity<F>((int)R);
+    std::vector<T> prev(nq);
+    for (size_t j = 0; j < nq; j++) { u64 b; memcpy(&b, raw.data() + 8 * j, 8); if (b > dsize) b %= dsize; prev[j] = f_pow<F>(g, b); }  // fri.rs:271-277 (quirk Q6: `>`)
+    const u8* bp = pr.fri_blob.data(); size_t left = pr.fri_blob.size();
+    for (size_t i = 0; i + 1 < R; i++) {
+      for (size_t j = 0; j < nq; j++) {
+        if (left < (size_t)(6 * e + 1) * 8) { *why = "FRI proof truncated"; return 0; }
+        const u64* pts = (const u64*)bp;
+        if (!canon(pts, 6 * e)) { *why = "FRI point not canonical"; return 0; }
+        const X x1 = load(pts), y1 = load(pts + e), x2 = load(pts + 2 * e), y2 = load(pts + 3 * e), x3 = load(pts + 4 * e), y3 = load(pts + 5 * e);
+        const u64 qlen = pts[6 * e];
+        if (qlen > ((u64)1 << 40) || left < (size_t)(6 * e + 1) * 8 + (size_t)qlen * e * 8) { *why = "FRI proof truncated"; return 0; }
+        const u64* quo = pts + 6 * e + 1;
+        if (!canon(quo, (size_t)qlen * e)) { *why = "quotient coefficient not canonical"; return 0; }
+        bp += (6 * e + 1) * 8 + qlen * e * 8; left -= (6 * e + 1) * 8 + qlen * e * 8;
+        const X X1 = e_from_base<F, E>(prev[j]);
+        if (!e_eq<F, E>(x1, X1)) { *why = "x1 is not the previous round's x3 (fri.rs:215)"; return 0; }
+        if (!e_eq<F, E>(e_from_base<F, E>(F::neg(prev[j])), x2)) { *why = "x2 != -x1 (fri.rs:216)"; return 0; }
+        const T x3b = F::mul(prev[j], prev[j]);
+        if (!e_eq<F, E>(e_from_base<F, E>(x3b), x3)) { *why = "x3 != x1^2 (fri.rs:217)"; return 0; }
+        // degree bound of the shipped quotient (fri.rs:219-224): trimmed degree + deg((x-x1)(x-x2)(x-x3))
+        size_t deg = 0;
+        for (size_t k = qlen; k-- > 0;) { bool nz = false; for (int l = 0; l < e; l++) nz = nz || quo[k * e + l] != 0; if (nz) { deg = k; break; } }
+        const u64 total = deg + 3;
+        if (total < 2 || total > ((u64)1 << (R - i))) { *why = "quotient degree out of bounds (fri.rs:222-223)"; return 0; }
+        // linearity against the DEEP-adjusted next-round value (fri.rs:226-234): the line through (x1,y1), (x2,y2) at alpha
+        const T dxi = f_inv<F>(F::sub(F::neg(prev[j]), prev[j]));               // 1 / (x2 - x1), base field
+        const X a = e_mul_base<F, E>(e_sub<F, E>(y2, y1), dxi);
+        const X b = e_sub<F, E>(y1, e_mul_base<F, E>(a, prev[j]));
+        const X lhs = e_add<F, E>(b, e_mul<F>(a, alphas[i]));
+        const X deep = e_add<F, E>(e_mul<F>(y3, e_sub<F, E>(x3, zs[i])), e_add<F, E>(B0[i], e_mul<F>(B1[i], alphas[i])));
+        if (!e_eq<F, E>(lhs, deep)) { *why = "DEEP-adjusted linearity check failed (fri.rs:234)"; return 0; }
+        // Merkle openings of y1, y2 in round i's tree (fri.rs:236-239; checked against round i's root and enforced — the reference
+        // discards check_proof's result and names the next round's root: DESIGN.md quirk Q13)
+        for (int s2 = 0; s2 < 2; s2++) {
+          size_t used = 0;
+          if (!check_path<F, E>(pr.fri_roots.data() + i * 32, bp, left, &used, s2 ? pts + 3 * e : pts + e, zae, why)) return 0;
+          bp += used; left -= used;
+        }
+        prev[j] = x3b;
+      }
+    }
+    if (left != 0) { *why = "trailing bytes in the FRI proof"; return 0; }
+    return 1;
+  }
+};
+
 }  // namespace ministark
 
 // ---- C entry points for the Python test / bench harness ---------------------------------------
@@ -220,4 +371,23 @@ size_t msh_proof_fri_roots(const msh_stark* h, u8* out, size_t cap) { return cop
 size_t msh_proof_fri_blob(const msh_stark* h, u8* out, size_t cap) { return copy_out(h->s.proof.fri_blob.data(), h->s.proof.fri_blob.size(), out, cap); }
 size_t msh_proof_challenges(const msh_stark* h, u64* out, size_t cap_elems) { return copy_out(h->s.proof.challenges.data(), h->s.proof.challenges.size() * 8, out, cap_elems * 8) / 8; }
 size_t msh_proof_num_polys(const msh_stark* h) { return h->s.proof.c; }
+// Stark::verify (src/starks.rs:171-235) of a proof given by its parts; `constrains` = the c constraint polynomials in coefficient
+// form ([c][N] canonical u64: what trace.derive_constrains() hands the reference's verifier).  1 accepted, 0 rejected, < 0 malformed;
+// the reason is copied to `why`.
+int msh_stark_verify(const msh_stark* h, const u64* constrains, size_t c, size_t N, const u8* arthur, size_t arthur_len, const u8* trace_commit,
+                     const u8* lde_commit, const u64* evals, size_t nevals, const u8* fri_roots, size_t nroots, const u8* blob, size_t blob_len,
+                     int zero_display_empty, char* why, size_t why_cap) {
+  StarkProof pr;
+  pr.arthur.assign(arthur, arthur + arthur_len);
+  memcpy(pr.trace_commit, trace_commit, 32); memcpy(pr.constrain_trace_commit, lde_commit, 32);
+  pr.evals.assign(evals, evals + nevals);
+  pr.fri_roots.assign(fri_roots, fri_roots + nroots * 32);
+  pr.fri_blob.assign(blob, blob + blob_len);
+  std::string reason;
+  int rc;
+  if (h->s.cfg.field == MS_FIELD_GOLDILOCKS) rc = Verifier<GL, 2>::run(h->s.cfg, constrains, c, N, pr, zero_display_empty, &reason);
+  else rc = Verifier<BB, 4>::run(h->s.cfg, constrains, c, N, pr, zero_display_empty, &reason);
+  if (why && why_cap) { size_t n = reason.size() < why_cap - 1 ? reason.size() : why_cap - 1; memcpy(why, reason.data(), n); why[n] = 0; }
+  return rc;
+}
 }

@@ -196,3 +196,23 @@ def test_sharded_proof_on_gpu(world, field, log_n):
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     calls = {int(k): v for k, v in res["calls"].items()}
     assert res["world"] == world and calls[0] >= 3 and calls[2] == 1 and calls[3] == 1
+
+
+@pytest.mark.parametrize("field,log_n", [(0, 10), (1, 9), (0, 20), (1, 18)])
+def test_prove_then_verify_roundtrip_on_gpu(mk, field, log_n):
+    """The reference's e2e flow (tests/e2e_goldilocks.rs:98-114) on the HIP build, up to BASELINE's full size: derive_constrains on
+    the verifier's copy, Stark::prove on the GPU, Stark::verify with the product's CPU verifier; a flipped proof bit is rejected."""
+    from mini_stark_amd.host import HostStark, build_host_library
+    from mini_stark_amd.stark import fibonacci_air
+    build_host_library()
+    ctx = mk(field)
+    steps = (1 << log_n) - 1
+    tt = fibonacci_air(ctx, steps)
+    hs = HostStark(ctx, 20, 8, steps, tt.constrain_number())
+    constrains = hs.derive_constrains(tt)
+    proof = hs.prove(tt)
+    assert hs.verify(constrains, proof), hs.last_verify_error
+    blob = bytearray(proof.fri_proof.blob)
+    blob[8 * ctx.e] ^= 1  # y1 of the first opening
+    proof.fri_proof = type(proof.fri_proof)(bytes(blob), device_resident=False)
+    assert not hs.verify(constrains, proof) and "linearity" in hs.last_verify_error

@@ -96,3 +96,53 @@ def test_stark_verify_deep_ali_and_mont64_input(emu, field):
     mt.data[:] = np.array([[int(v) * R % p for v in row] for row in tt.data], dtype=np.uint64)
     mp = HostStark(mctx, 20, blowup, steps, mt.constrain_number()).prove(mt)
     assert mp.arthur == proof.arthur and mp.fri_proof.blob == proof.fri_proof.blob and mp.trace_commit == proof.trace_commit
+
+
+@pytest.mark.parametrize("field,steps,blowup", [(0, 9, 2), (1, 7, 2), (0, 63, 8), (1, 31, 4), (0, 255, 8)])
+def test_prove_then_verify_roundtrip(emu, field, steps, blowup):
+    """The reference's integration tests (tests/e2e_goldilocks.rs:98-114, tests/e2e_babybear.rs): derive_constrains on the verifier's
+    copy, prove, verify — here with the product's own CPU verifier (stark_host.cpp: Stark::verify / Fri::verify / check_proof),
+    no oracle involved; then every part of the proof is tampered with in turn and must be rejected."""
+    import copy
+    ctx = ms.Context(field, lib_path=emu)
+    tt = fibonacci_air(ctx, steps)
+    hs = HostStark(ctx, 20, blowup, steps, tt.constrain_number())
+    constrains = hs.derive_constrains(tt)
+    proof = hs.prove(tt)
+    assert hs.verify(constrains, proof), hs.last_verify_error
+    p = 2**64 - 2**32 + 1 if field == 0 else 2013265921
+
+    def rejected(pr, cs=constrains):
+        ok = hs.verify(cs, pr)
+        assert not ok and hs.last_verify_error
+        return hs.last_verify_error
+
+    bad = copy.deepcopy(proof); bad.trace_commit = bytes([proof.trace_commit[0] ^ 1]) + proof.trace_commit[1:]
+    assert "trace commit" in rejected(bad)
+    bad = copy.deepcopy(proof); bad.constrain_queries = proof.constrain_queries.copy(); bad.constrain_queries[0, 1, 0] = (int(bad.constrain_queries[0, 1, 0]) + 1) % p
+    assert "evaluation" in rejected(bad)
+    bad = copy.deepcopy(proof); bad.validity_queries = proof.validity_queries.copy(); bad.validity_queries[0, 0] = (int(bad.validity_queries[0, 0]) + 1) % p
+    assert "validity" in rejected(bad)
+    bad = copy.deepcopy(proof); a = bytearray(proof.arthur); a[70] ^= 1; bad.arthur = bytes(a)          # a DEEP coefficient of round 1
+    rejected(bad)
+    bad = copy.deepcopy(proof); r = bytearray(proof.fri_roots[1]); r[5] ^= 1; bad.fri_roots = [proof.fri_roots[0], bytes(r)] + proof.fri_roots[2:]
+    assert "root" in rejected(bad)
+    blob = proof.fri_proof.blob
+    e = ctx.e
+    for off, what in ((8 * e, "linearity"), (8 * 5 * e, "linearity"), (len(blob) - 1, "Merkle")):
+        bad = copy.deepcopy(proof); b2 = bytearray(blob); b2[off] ^= 1
+        bad.fri_proof = type(proof.fri_proof)(bytes(b2), device_resident=False)
+        assert what in rejected(bad)
+    # the shipped quotient polynomials are only degree-bounded by the reference's verifier (`let _ = quotient / vanishing_poly`,
+    # fri.rs:219-225): a changed low coefficient is accepted there and here; a non-canonical one is malformed input
+    bad = copy.deepcopy(proof); b2 = bytearray(blob); b2[(6 * e + 1) * 8] ^= 1
+    bad.fri_proof = type(proof.fri_proof)(bytes(b2), device_resident=False)
+    assert hs.verify(constrains, bad)
+    bad = copy.deepcopy(proof); bad.fri_proof = type(proof.fri_proof)(blob[:-8], device_resident=False)
+    rejected(bad)
+    # a different AIR instance (other witness) does not verify against this proof
+    other = hs.derive_constrains(fibonacci_air(ctx, steps, secret_b=3))
+    assert "evaluation" in rejected(proof, other)
+    # round 0's root is NOT bound by the transcript (fri.rs:73-82 never sends it): a wrong root0 is only caught by the Merkle paths
+    bad = copy.deepcopy(proof); r = bytearray(proof.fri_roots[0]); r[0] ^= 1; bad.fri_roots = [bytes(r)] + proof.fri_roots[1:]
+    assert "Merkle" in rejected(bad)
