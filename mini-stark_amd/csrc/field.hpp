@@ -99,6 +99,20 @@ template <class F> MS_HD typename F::T f_pow(typename F::T a, u64 e) {
 }
 template <class F> MS_HD typename F::T f_inv(typename F::T a) { return f_pow<F>(a, F::P - 2); }
 
+// Goldilocks x^(p-2) with the 72-multiplication addition chain for p - 2 = 2^64 - 2^32 - 1 (63 squarings + 9 products)
+MS_HD u64 gl_inv_chain(u64 x) {
+  auto sqn = [](u64 v, int n) { for (int i = 0; i < n; i++) v = GL::mul(v, v); return v; };
+  const u64 t2 = GL::mul(GL::mul(x, x), x);            // x^(2^2 - 1)
+  const u64 t3 = GL::mul(GL::mul(t2, t2), x);          // x^(2^3 - 1)
+  const u64 t6 = GL::mul(sqn(t3, 3), t3);
+  const u64 t12 = GL::mul(sqn(t6, 6), t6);
+  const u64 t24 = GL::mul(sqn(t12, 12), t12);
+  const u64 t30 = GL::mul(sqn(t24, 6), t6);
+  const u64 t31 = GL::mul(GL::mul(t30, t30), x);       // x^(2^31 - 1)
+  const u64 t63 = GL::mul(sqn(t31, 32), t31);          // x^(2^63 - 2^32 + 2^31 - 1)
+  return GL::mul(GL::mul(t63, t63), x);                // x^(2^64 - 2^32 - 1)
+}
+
 // [ark-mem] Radix2EvaluationDomain::new(n).group_gen: GENERATOR^((p-1)/2^s) squared (s - log2 n) times
 template <class F> inline typename F::T f_root_of_unity(int log_n) {
   typename F::T w = f_pow<F>(F::from_u64(F::GENERATOR), (F::P - 1) >> F::TWO_ADICITY);

@@ -97,6 +97,7 @@ template <class F> struct Ctx : CtxBase {
 
   int device = 0, zae = 1, trace_mont = 0;
   int lde_linear = 1;  // MS_LDE_LINEAR=0 disables the linear-provenance shortcut of lde_compute (A/B measurements)
+  int fri_pointwise = 1;  // MS_FRI_POINTWISE=0: codewords of FRI rounds >= 1 by NTT of the round polynomial instead of the evaluation-domain fold
   msrt::Stream* own_stream = nullptr;
   msrt::Stream* stream = nullptr;
   void* pinned = nullptr; size_t pinned_cap = 0;
@@ -495,6 +496,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_TH512")) ntt_th512 = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
+    if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MIN")) ntt_fast_min = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
     if (const char* e = getenv("MS_SHARD_MIN_LEAVES")) { long v = atol(e); if (v >= 1) shard_min_leaves = (size_t)v; }
@@ -796,10 +798,42 @@ template <class F> struct Ctx : CtxBase {
   // codeword + tree of rounds[i] from its coefficient limbs (ncoef_in valid coefficients)
   // `nonzero_limbs`: limbs >= this are identically zero (round 0: extend_poly embeds base coefficients), so their
   // transform is all zeros and is not computed
-  int round_commit(Round* r, size_t ncoef_in, int nonzero_limbs = E) {
+  // `prev` != nullptr: the codeword is folded out of prev's codeword in the evaluation domain (FriFoldEvalKernel) instead of
+  // transforming the round polynomial — same values, a quarter of the arithmetic
+  int round_commit(Round* r, size_t ncoef_in, int nonzero_limbs = E, const Round* prev = nullptr, const XE* alpha = nullptr) {
     if (ctz64(r->D) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "FRI domain larger than the field's two-adicity");
     RQ(tree_shape(r->D, 2, 2, &r->ts));  // starks.rs:290-295: leafs_per_node 2, inner_children 2
     r->m = 0;
+    if constexpr (F::ID == 0 && E == 2) {
+      const bool shard_next = shardable(r->D / 2);
+      if (prev && fri_pointwise && cur_z.c[1] != 0 && prev->D == 2 * r->D && prev->ts.sharded == shard_next) {
+        Plan* pl;
+        RQ(get_plan(ctz64(prev->D), 0, false, &pl));   // w_D^e tables of the previous domain
+        typedef mspoly::FriFoldEvalKernel<F> FK;
+        typename FK::Params fp;
+        const size_t W = (size_t)sh_world;
+        const size_t m_out = shard_next ? r->D / (2 * W) : r->D;
+        const size_t local = shard_next ? 2 * m_out : r->D;       // elements per limb held here
+        if (shard_next) r->m = m_out;
+        if (r->cw.ensure(local * E * sizeof(T))) return fail(MS_ERR_NOMEM, "codeword");
+        fp.src = prev->cw.template as<T>(); fp.src_limb_stride = shard_next ? 2 * prev->m : prev->D;
+        fp.dst = r->cw.template as<T>(); fp.dst_limb_stride = local;
+        fp.m_out = m_out; fp.log_m = (u32)ctz64(m_out); fp.groups = shard_next ? 2 : 1; fp.shard_W = shard_next ? (u32)W : 0; fp.shard_k = (u32)sh_rank;
+        fp.tw_lo = pl->tw_lo.template as<T>(); fp.tw_hi = pl->tw_hi.template as<T>(); fp.lo_bits = (u32)pl->lo_bits; fp.log_D = (u32)ctz64(prev->D);
+        fp.alpha = *alpha;
+        const XE c = e_add<F, E>(cur_B[0], e_mul<F>(cur_B[1], *alpha));   // B(alpha), fri.rs:99
+        fp.c2 = e_add<F, E>(c, c);
+        fp.z0 = cur_z.c[0]; fp.z1 = cur_z.c[1];
+        fp.z1_nr = F::mul(F::from_u64(F::NR2), cur_z.c[1]); fp.z1sq_nr = F::mul(fp.z1_nr, cur_z.c[1]);
+        fp.inv2 = f_inv<F>(F::from_u64(2));
+        const size_t total = m_out * fp.groups;
+        next_bytes = (double)total * E * sizeof(T) * 3;   // two inputs read, one output written per element
+        CK(run<FK>(K_FOLD, grid1(total, FK::THREADS * FK::ITEMS), 1, FK::THREADS, 0, fp));
+        if (shard_next) RQ((tree_build_sharded<E>(r->cw.template as<T>(), m_out, 1, 2 * m_out, 2, r->ts, r->nodes)));
+        else RQ((tree_build<E>(r->cw.template as<T>(), 0, 1, r->D, 1, r->ts, r->nodes)));
+        return 0;
+      }
+    }
     if (shardable(r->D / 2)) {  // leaf group j = codeword elements 2j, 2j+1: rank k owns the groups k (mod world) = two cosets of size m
       const size_t m = r->D / (2 * (size_t)sh_world);
       r->m = m;
@@ -952,7 +986,7 @@ template <class F> struct Ctx : CtxBase {
       RQ(suffix_horner(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), nr->cap, 0, 1, nullptr));
       nq_coef = m - 1;
     }
-    RQ(round_commit(nr, nq_coef));
+    RQ(round_commit(nr, nq_coef, E, pr, &a));
     size_t nc;
     RQ(read_degree_and_root(nr->poly.template as<T>(), nr->cap, nq_coef, nr, &nc, root));
     nr->ncoef = nc;

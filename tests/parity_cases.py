@@ -67,7 +67,7 @@ def case_merkle(mk, field, leaf_num, ext, lpn, ic, special=False):
         assert root == oroot
 
 
-def drive(sess, field, trace, blowup, nq_fri, seed, rounds=None, q_ood=2, read_big=True):
+def drive(sess, field, trace, blowup, nq_fri, seed, rounds=None, q_ood=2, read_big=True, base_field_z_rounds=()):
     """Runs one full prove on `sess` (oracle Session or mini_stark_amd Context) with challenges
     drawn from SplitMix64(seed); returns the list of stage outputs."""
     p, e = MODULUS[field], EXT[field]
@@ -104,6 +104,8 @@ def drive(sess, field, trace, blowup, nq_fri, seed, rounds=None, q_ood=2, read_b
     out.append(("fri_root0", root))
     for i in range(1, rounds):
         z = [rng.field(p) for _ in range(e)]
+        if i in base_field_z_rounds:  # a DEEP point in the base field: the kernels' evaluation-domain fold must fall back to the transform
+            z = [z[0]] + [0] * (e - 1)
         rc, B = sess.fri_deep(z)
         assert rc == 0
         out.append((f"B{i}", B.tolist()))
@@ -163,6 +165,14 @@ def case_prove(mk, field, log_n, blowup, nq_fri=2, seed=77, read_big=True, steps
     for (ka, va), (kb, vb) in zip(a, b):
         assert ka == kb
         assert va == vb, f"stage output {ka} differs"
+
+
+def case_prove_base_field_deep_points(mk, field, log_n=6, blowup=8):
+    """FRI rounds whose DEEP point z lies in the base field (and rounds mixing both kinds)."""
+    trace = fibonacci_trace_fast(field, 1 << log_n)
+    a = drive(mk(field), field, trace, blowup, 1, seed=3, base_field_z_rounds=(1, 3, 4))
+    b = drive(orc.Session(field), field, trace, blowup, 1, seed=3, base_field_z_rounds=(1, 3, 4))
+    assert a == b
 
 
 def case_errors(mk, field):
