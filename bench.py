@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-rows", type=int, default=20, help="log2 of trace rows (BASELINE configs[1]: 20)")
     ap.add_argument("--blowup", type=int, default=8)
     ap.add_argument("--field", type=int, default=0, help="0 Goldilocks, 1 BabyBear")
