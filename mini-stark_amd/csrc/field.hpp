@@ -60,6 +60,7 @@ struct GL {
   // twiddle tables hold to_tw(w); mul_tw(a, to_tw(w)) == a * w.  Nothing to gain for Goldilocks: identity.
   static MS_HD T to_tw(T w) { return w; }
   static MS_HD T mul_tw(T a, T w_tab) { return mul(a, w_tab); }
+  static MS_HD T from_tw(T w_tab) { return w_tab; }
 };
 
 struct BB {
@@ -90,6 +91,7 @@ struct BB {
   // reduction (a * wR / R = a * w), and the product of two table entries is again in table form
   static MS_HD T to_tw(T w) { return (T)((((u64)w) << 32) % P); }
   static MS_HD T mul_tw(T a, T w_tab) { return redc((u64)a * (u64)w_tab); }
+  static MS_HD T from_tw(T w_tab) { return redc((u64)w_tab); }
 };
 
 template <class F> MS_HD typename F::T f_pow(typename F::T a, u64 e) {

@@ -804,12 +804,14 @@ template <class F> struct Ctx : CtxBase {
     if (ctz64(r->D) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "FRI domain larger than the field's two-adicity");
     RQ(tree_shape(r->D, 2, 2, &r->ts));  // starks.rs:290-295: leafs_per_node 2, inner_children 2
     r->m = 0;
-    if constexpr (F::ID == 0 && E == 2) {
+    {
       const bool shard_next = shardable(r->D / 2);
-      if (prev && fri_pointwise && cur_z.c[1] != 0 && prev->D == 2 * r->D && prev->ts.sharded == shard_next) {
+      bool z_outside_base = false;   // then y - z != 0 on the whole (base-field) domain
+      for (int l = 1; l < E; l++) z_outside_base = z_outside_base || cur_z.c[l] != 0;
+      if (prev && fri_pointwise && z_outside_base && prev->D == 2 * r->D && prev->ts.sharded == shard_next) {
         Plan* pl;
         RQ(get_plan(ctz64(prev->D), 0, false, &pl));   // w_D^e tables of the previous domain
-        typedef mspoly::FriFoldEvalKernel<F> FK;
+        typedef mspoly::FriFoldEvalKernel<F, E> FK;
         typename FK::Params fp;
         const size_t W = (size_t)sh_world;
         const size_t m_out = shard_next ? r->D / (2 * W) : r->D;
@@ -823,8 +825,7 @@ template <class F> struct Ctx : CtxBase {
         fp.alpha = *alpha;
         const XE c = e_add<F, E>(cur_B[0], e_mul<F>(cur_B[1], *alpha));   // B(alpha), fri.rs:99
         fp.c2 = e_add<F, E>(c, c);
-        fp.z0 = cur_z.c[0]; fp.z1 = cur_z.c[1];
-        fp.z1_nr = F::mul(F::from_u64(F::NR2), cur_z.c[1]); fp.z1sq_nr = F::mul(fp.z1_nr, cur_z.c[1]);
+        fp.z = cur_z;
         fp.inv2 = f_inv<F>(F::from_u64(2));
         const size_t total = m_out * fp.groups;
         next_bytes = (double)total * E * sizeof(T) * 3;   // two inputs read, one output written per element

@@ -350,73 +350,97 @@ template <class F, int E> struct SuffixHornerKernel {
 };
 
 // ---------------------------------------------------------------- FRI fold in the evaluation domain
-// The codeword of FRI round i+1 straight from the codeword of round i (Goldilocks Fp2), without a transform:
+// The codeword of FRI round i+1 straight from the codeword of round i, without a transform:
 // with f = even(x^2) + x odd(x^2) the round polynomial is g(y) = (even(y) + alpha odd(y) - c) / (y - z)
 // (fri.rs:96-101: fold, subtract B(alpha), exact division by (x - z)), and on the next domain y = x^2
-//   even(y) = (f(x) + f(-x)) / 2,   odd(y) = (f(x) - f(-x)) / (2x),   1/(y - z) = (y - z0 + z1 u) / ((y - z0)^2 - 7 z1^2).
+//   even(y) = (f(x) + f(-x)) / 2,   odd(y) = (f(x) - f(-x)) / (2x),   1/(y - z) = C(y) / n(y)
+// with C the product of the conjugates of (y - z) and n its norm down to the base field:
+//   Fp2 (Goldilocks):  C = (y - z0) + z1 u,                    n = (y - z0)^2 - 7 z1^2
+//   Fp4 (BabyBear):    A = (y - z0) - z1 u, M = A^2 - (z2 + z3 u)^2 (u - 11), C = (A conj(M), (z2 + z3 u) conj(M)), n = M0^2 - 11 M1^2.
 // Field arithmetic is exact, so these are the values the size-D/2 NTT of g's coefficients (fri.rs:350) would give.
-// z1 != 0 keeps the norm non-zero (7 is a non-residue); the host falls back to the NTT otherwise.
-// One thread owns ITEMS outputs and inverts their norms together (Montgomery's trick + one 72-multiplication inversion).
+// z outside the base field keeps the norm non-zero; the host falls back to the NTT otherwise.
+// One thread owns ITEMS outputs and inverts their norms together (Montgomery's trick + one field inversion).
 // Index maps: output j = t*m_out + i (t < groups), inputs f(x) at t*2*m_out + i and f(-x) m_out further, domain index
 // r = i (replicated round) or 2*(rank + W*i) + t (sharded round: this rank's two cosets).
-template <class F> struct FriFoldEvalKernel {
+template <class F> MS_HD typename F::T fold_base_inv(typename F::T x) { return f_inv<F>(x); }
+template <> MS_HD u64 fold_base_inv<GL>(u64 x) { return gl_inv_chain(x); }
+template <class F, int E> struct FriFoldEvalKernel {
   typedef typename F::T T;
+  typedef Ext<F, E> X;
+  static_assert(E == 2 || E == 4, "quadratic or quartic tower");
   static constexpr int THREADS = mspoly::THREADS;
   static constexpr int ITEMS = 8;
   struct Params {
     const T* src; size_t src_limb_stride; T* dst; size_t dst_limb_stride;
     size_t m_out; u32 log_m /* log2 m_out */, groups, shard_W, shard_k;
-    const T* tw_lo; const T* tw_hi; u32 lo_bits, log_D;   // w_D^e = tw_lo[e & mask] * tw_hi[e >> lo_bits] (the size-D forward plan)
-    Ext<F, 2> alpha, c2 /* 2 (B0 + B1 alpha) */;
-    T z0, z1, z1sq_nr /* NR * z1^2 */, z1_nr /* NR * z1 */, inv2;
+    const T* tw_lo; const T* tw_hi; u32 lo_bits, log_D;   // F::to_tw(w_D^e) = tw_lo[e & mask] * tw_hi[e >> lo_bits] (the size-D forward plan)
+    X alpha, c2 /* 2 (B0 + B1 alpha) */, z;
+    T inv2;
   };
-  static_assert(F::ID == 0, "Goldilocks only (table entries are plain field elements; gl_inv_chain)");
   static MS_HD int nphases(const Params&) { return 1; }
-  static MS_DEV T w_pow(const Params& p, size_t e) {
+  static MS_DEV T w_tab(const Params& p, size_t e) {
     T tw = p.tw_lo[e & (((size_t)1 << p.lo_bits) - 1)];
     const size_t eh = e >> p.lo_bits;
     if (eh) tw = F::mul_tw(tw, p.tw_hi[eh]);
     return tw;
   }
+  // conjugate product C and base-field norm n of (y - z), yd = y - z0
+  static MS_DEV void inv_parts(const Params& p, T yd, X* C, T* n) {
+    const T nr = F::from_u64(F::NR2);
+    if constexpr (E == 2) {
+      C->c[0] = yd; C->c[1] = p.z.c[1];
+      *n = F::sub(F::mul(yd, yd), F::mul(nr, F::mul(p.z.c[1], p.z.c[1])));
+    } else {
+      Ext<F, 2> A, zb, K;
+      A.c[0] = yd; A.c[1] = F::neg(p.z.c[1]);
+      zb.c[0] = p.z.c[2]; zb.c[1] = p.z.c[3];
+      K = e_mul_nr4<F>(e_mul<F>(zb, zb));
+      const Ext<F, 2> M = e_sub<F, 2>(e_mul<F>(A, A), K);
+      Ext<F, 2> Mc; Mc.c[0] = M.c[0]; Mc.c[1] = F::neg(M.c[1]);
+      *n = F::sub(F::mul(M.c[0], M.c[0]), F::mul(nr, F::mul(M.c[1], M.c[1])));
+      const Ext<F, 2> c0 = e_mul<F>(A, Mc), c1 = e_mul<F>(zb, Mc);
+      C->c[0] = c0.c[0]; C->c[1] = c0.c[1]; C->c[2] = c1.c[0]; C->c[3] = c1.c[1];
+    }
+  }
   static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
     const size_t total = p.m_out * p.groups, Dm = ((size_t)1 << p.log_D) - 1;
     const size_t j0 = (size_t)bx * ((size_t)nthreads * ITEMS) + tid;
-    T t0[ITEMS], t1[ITEMS], nrm[ITEMS], pre[ITEMS];
+    X tt[ITEMS]; T nrm[ITEMS], pre[ITEMS];
     T run = F::from_u64(1);
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
       const size_t j = j0 + (size_t)it * nthreads;
-      t0[it] = 0; t1[it] = 0; nrm[it] = F::from_u64(1);
+      tt[it] = e_zero<F, E>(); nrm[it] = F::from_u64(1);
       if (j < total) {
         const size_t t = j >> p.log_m, i = j & (p.m_out - 1);
         const size_t ia = t * 2 * p.m_out + i, ib = ia + p.m_out;
         const size_t r = p.shard_W ? 2 * ((size_t)p.shard_k + (size_t)p.shard_W * i) + t : i;
-        const T a0 = p.src[ia], a1 = p.src[p.src_limb_stride + ia], b0 = p.src[ib], b1 = p.src[p.src_limb_stride + ib];
-        const T s0 = F::add(a0, b0), s1 = F::add(a1, b1), d0 = F::sub(a0, b0), d1 = F::sub(a1, b1);
-        const T xinv = w_pow(p, (Dm + 1 - r) & Dm);                                         // x^-1 = w_D^(D - r)
-        Ext<F, 2> u; u.c[0] = F::mul(p.alpha.c[0], xinv); u.c[1] = F::mul(p.alpha.c[1], xinv);  // alpha / x
-        Ext<F, 2> d; d.c[0] = d0; d.c[1] = d1;
-        const Ext<F, 2> v = e_mul<F>(u, d);                                                 // alpha (f(x) - f(-x)) / x
-        const T n0 = F::sub(F::add(s0, v.c[0]), p.c2.c[0]), n1 = F::sub(F::add(s1, v.c[1]), p.c2.c[1]);  // 2 (folded - c)
-        const T y = w_pow(p, (2 * r) & Dm);                                                 // y = x^2
-        const T yd = F::sub(y, p.z0);
-        nrm[it] = F::sub(F::mul(yd, yd), p.z1sq_nr);                                        // norm of (y - z): never zero for z1 != 0
-        // 2 (folded - c) * conj(y - z) = (n0 + n1 u)(yd + z1 u)
-        t0[it] = F::add(F::mul(n0, yd), F::mul(n1, p.z1_nr));
-        t1[it] = F::add(F::mul(n0, p.z1), F::mul(n1, yd));
+        X a, b;
+#pragma unroll
+        for (int l = 0; l < E; l++) { a.c[l] = p.src[(size_t)l * p.src_limb_stride + ia]; b.c[l] = p.src[(size_t)l * p.src_limb_stride + ib]; }
+        const X s = e_add<F, E>(a, b), d = e_sub<F, E>(a, b);
+        const T xinv = w_tab(p, (Dm + 1 - r) & Dm);                       // table form of x^-1 = w_D^(D - r)
+        X u;                                                               // alpha / x
+#pragma unroll
+        for (int l = 0; l < E; l++) u.c[l] = F::mul_tw(p.alpha.c[l], xinv);
+        const X num = e_sub<F, E>(e_add<F, E>(s, e_mul<F>(u, d)), p.c2);   // 2 (folded - c)
+        const T y = F::from_tw(w_tab(p, (2 * r) & Dm));                   // y = x^2
+        X C;
+        inv_parts(p, F::sub(y, p.z.c[0]), &C, &nrm[it]);
+        tt[it] = e_mul<F>(num, C);
       }
       pre[it] = run;                 // product of the norms before this one
       run = F::mul(run, nrm[it]);
     }
-    T inv = F::mul(gl_inv_chain(run), p.inv2);   // 1 / (2 * product of all norms)
+    T inv = F::mul(fold_base_inv<F>(run), p.inv2);   // 1 / (2 * product of all norms)
 #pragma unroll
     for (int it = ITEMS - 1; it >= 0; it--) {
       const size_t j = j0 + (size_t)it * nthreads;
-      const T ni = F::mul(inv, pre[it]);         // 1 / (2 norm_it)
+      const T ni = F::mul(inv, pre[it]);             // 1 / (2 norm_it)
       inv = F::mul(inv, nrm[it]);
       if (j < total) {
-        p.dst[j] = F::mul(t0[it], ni);
-        p.dst[p.dst_limb_stride + j] = F::mul(t1[it], ni);
+#pragma unroll
+        for (int l = 0; l < E; l++) p.dst[(size_t)l * p.dst_limb_stride + j] = F::mul(tt[it].c[l], ni);
       }
     }
   }
