@@ -25,7 +25,7 @@ if on_gpu:
     ctx = ms.Context(field)
     xchg = ShardExchange(grp, ctx, cap, staged=True, buffer_device=torch.device("cuda", 0))
 else:
-    ctx = ms.Context(field, lib_path=os.path.join(ROOT, "tests", "emu", "libministark_emu.so"))
+    ctx = ms.Context(field, lib_path=os.environ.get("MS_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "libministark_emu.so"))  # MS_EMU_LIB: sanitizer builds
     xchg = ShardExchange(grp, ctx, cap)
 trace = fibonacci_trace_fast(field, N)
 got = pc.drive(ctx, field, trace, blowup, 2, seed=11, read_big=False)

@@ -1,0 +1,27 @@
+"""Parity cases of tests/parity_cases.py on a sanitizer build of the kernel-emulation library (tools/asan_check.sh)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import mini_stark_amd as ms
+import parity_cases as pc
+EMU = os.environ.get('MS_EMU_LIB', '/tmp/libministark_emu_asan.so')
+cache = {}
+def mk(field, fresh=False):
+    if fresh: return ms.Context(field, lib_path=EMU)
+    if field not in cache: cache[field] = ms.Context(field, lib_path=EMU)
+    return cache[field]
+for field in (0, 1):
+    for log_n in (0, 1, 3, 5, 9, 10, 11, 12, 13, 14):
+        pc.case_ntt(mk, field, log_n)
+    pc.case_coset_lde(mk, field, 4, 8); pc.case_coset_lde(mk, field, 9, 4)
+    for a in [(16, 1, 2, 2), (16, 1, 4, 4), (3, 1, 2, 2), (4096, 1, 2, 2), (6144, 1, 6, 2), (64, pc.EXT[field], 2, 2), (1 << 13, pc.EXT[field], 2, 2)]:
+        pc.case_merkle(mk, field, *a, special=True)
+    for lpn, ext in ((6, 1), (16, 1), (2, pc.EXT[field])):
+        pc.case_merkle_length_sweep(mk, field, lpn, ext)
+    for log_n, blowup in ((4, 2), (3, 8), (6, 8), (10, 8)):
+        pc.case_prove(mk, field, log_n, blowup)
+    pc.case_prove_base_field_deep_points(mk, field)
+    pc.case_errors(mk, field)
+    pc.case_prove_wide(mk, field, log_n=6, w=64)
+    pc.case_general_closure(mk, field)
+    pc.case_merkle_prove(mk, field)
+print("asan run complete")
