@@ -16,7 +16,9 @@ from oracle import oracle as orc  # noqa: E402
 
 field, log_n, blowup = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 os.environ["MS_SHARD_MIN_LEAVES"] = sys.argv[4] if len(sys.argv) > 4 else "16"
-on_gpu = len(sys.argv) > 5 and sys.argv[5] == "gpu"   # the real HIP library, all ranks on GPU 0, payloads staged through host tensors for gloo
+mode = sys.argv[5] if len(sys.argv) > 5 else ""
+on_gpu = mode in ("gpu", "gpu-self")   # the real HIP library, all ranks on GPU 0, payloads staged through host tensors for gloo
+self_check = mode == "gpu-self"        # sizes beyond the oracle's reach: compare with an UNSHARDED proof of the same library instead
 grp = Group("gloo")
 N = 1 << log_n
 cap = 32 * N * blowup // grp.world + (1 << 20)  # leaf digests of the largest commitment / world + query-phase paths
@@ -29,7 +31,10 @@ else:
     xchg = ShardExchange(grp, ctx, cap)
 trace = fibonacci_trace_fast(field, N)
 got = pc.drive(ctx, field, trace, blowup, 2, seed=11, read_big=False)
-want = pc.drive(orc.Session(field), field, trace, blowup, 2, seed=11, read_big=False)
+if self_check:
+    want = pc.drive(ms.Context(field), field, trace, blowup, 2, seed=11, read_big=False)
+else:
+    want = pc.drive(orc.Session(field), field, trace, blowup, 2, seed=11, read_big=False)
 assert len(got) == len(want)
 for (ka, va), (kb, vb) in zip(got, want):
     assert ka == kb and va == vb, f"rank {grp.rank}: stage output {ka} differs from the oracle"

@@ -221,3 +221,19 @@ def test_prove_then_verify_roundtrip_on_gpu(mk, field, log_n):
     blob[8 * ctx.e] ^= 1  # y1 of the first opening
     proof.fri_proof = type(proof.fri_proof)(bytes(blob), device_resident=False)
     assert not hs.verify(constrains, proof) and "linearity" in hs.last_verify_error
+
+
+def test_sharded_full_size_matches_unsharded():
+    """BASELINE configs[1] size (2^20 rows, blowup 8) proved by 2 ranks sharing the GPU (default MS_SHARD_MIN_LEAVES: the LDE and the
+    eight largest FRI rounds are sharded): every commitment, DEEP value and the 64 MiB FRI proof equal the unsharded proof's."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29961", os.path.join(here, "shard_worker.py"), "0", "20", "8", "32768", "gpu-self"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    calls = {int(k): v for k, v in res["calls"].items()}
+    assert calls[0] == 9 and calls[1] == 9 and calls[2] == 1 and calls[3] == 1
