@@ -362,6 +362,20 @@ template <class F> struct Ctx : CtxBase {
     return 0;
   }
 
+  // ------------------------------------------------------------------ pool of zeroed device words
+  // Counters that kernels bump (deferred-block lists, the degree result) must start at zero.  One memset clears a 256 KiB
+  // pool; zero_alloc hands out fresh pieces of it and clears it again only when it runs out (stream order keeps earlier
+  // users ahead of the clear) — a proof needs ~50 such counters, i.e. one memset instead of ~50 four-microsecond fills.
+  DevBuf d_zero; size_t zero_used = 0, zero_cap = 0;
+  int zero_alloc(size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (!d_zero.p) { if (d_zero.ensure(256 << 10)) return fail(MS_ERR_NOMEM, "zero pool"); zero_cap = 256 << 10; zero_used = zero_cap; }
+    if (bytes > zero_cap) return fail(MS_ERR_NOMEM, "zero pool request too large");
+    if (zero_used + bytes > zero_cap) { CK(msrt::memset_dev(d_zero.p, 0, zero_cap, stream)); zero_used = 0; }
+    *out = d_zero.as<u8>() + zero_used; zero_used += bytes;
+    return 0;
+  }
+
   // ------------------------------------------------------------------ Merkle
   // sharded (ms_set_shard): this rank holds the subtree over leaf groups [rank*Mloc, (rank+1)*Mloc) followed by the replicated top
   // (world subtree roots and the levels above); local_nodes = nodes held here, root last in both cases
@@ -387,12 +401,13 @@ template <class F> struct Ctx : CtxBase {
     // deferred pad-only blocks: OVF_LISTS lists, list l fed by the workgroups bx = l (mod OVF_LISTS); capacity = all their threads
     const size_t nwg = grid1(ngroups, msmerkle::THREADS), lists = msmerkle::OVF_LISTS;
     const size_t cap = ((nwg + lists - 1) / lists) * msmerkle::THREADS;
-    if (d_ovf.ensure(lists * 4 + lists * cap * msmerkle::OVF_WORDS * 4)) return fail(MS_ERR_NOMEM, "deferred-block lists");
-    CK(msrt::memset_dev(d_ovf.p, 0, lists * 4, stream));
+    if (d_ovf.ensure(lists * cap * msmerkle::OVF_WORDS * 4)) return fail(MS_ERR_NOMEM, "deferred-block lists");
+    void* counters;
+    RQ(zero_alloc(lists * 4, &counters));
     typename msmerkle::LeafHashKernel<F, EL>::Params lp;
     lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
     lp.width = width; lp.lpn = (u32)lpn; lp.zero_as_empty = zae; lp.ngroups = ngroups; lp.nodes = out;
-    lp.ovf_count = d_ovf.as<u32>(); lp.ovf = d_ovf.as<u32>() + lists; lp.ovf_cap = (u32)cap;
+    lp.ovf_count = reinterpret_cast<u32*>(counters); lp.ovf = d_ovf.as<u32>(); lp.ovf_cap = (u32)cap;
     next_bytes = (double)ngroups * (lpn * EL * sizeof(T) + 32);
     CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
     msmerkle::PadOnlyBlockKernel::Params pp{lp.ovf_count, lp.ovf, (u32)cap, out};
@@ -511,14 +526,14 @@ template <class F> struct Ctx : CtxBase {
   ~Ctx() {
     for (auto& kv : plans) { kv.second->tw_lo.release(); kv.second->tw_hi.release(); kv.second->vtw.release(); kv.second->w0.release(); for (auto& b : kv.second->w_r) b.release(); delete kv.second; }
     for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
-    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf};
+    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero};
     for (DevBuf* b : bufs) b->release();
     if (pinned) msrt::free_host(pinned);
     if (own_stream) msrt::stream_destroy(own_stream);
   }
   int ext_degree() const override { return E; }
   void bind_device() const override { msrt::set_device(device); }
-  int set_stream(void* s) override { stream = s ? reinterpret_cast<msrt::Stream*>(s) : own_stream; return 0; }
+  int set_stream(void* s) override { stream = s ? reinterpret_cast<msrt::Stream*>(s) : own_stream; zero_used = zero_cap; return 0; }
   int synchronize() override { CK(msrt::sync(stream)); return 0; }
 
   static unsigned grid1(size_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -851,9 +866,9 @@ template <class F> struct Ctx : CtxBase {
     return 0;
   }
   int read_degree_and_root(const T* poly, size_t limb_stride, size_t n, Round* r, size_t* ncoef, u8* root) {
-    if (d_deg.ensure(64)) return fail(MS_ERR_NOMEM, "deg");
-    unsigned long long* dres = d_deg.as<unsigned long long>();
-    CK(msrt::memset_dev(dres, 0, 8, stream));
+    void* zr;
+    RQ(zero_alloc(8, &zr));
+    unsigned long long* dres = reinterpret_cast<unsigned long long*>(zr);
     if (n) {
       typename mspoly::DegreeKernel<F, E>::Params dp{poly, limb_stride, n, dres};
       CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
