@@ -277,3 +277,16 @@ def test_fri_roundtrip_fri_rs_426():
         assert ok == 1
         bad = bytearray(proof); bad[8 * ext] ^= 1  # corrupt y1
         assert orc.fri_verify(field, ext, rounds, betas, zs, Bs, als, b"".join(roots), bytes(bad)) == 0
+
+
+def test_oracle_matches_committed_proof_digests():
+    """tests/golden/oracle_proof_digests.json (generated by tests/golden/gen_oracle_proof_digests.py from this oracle, not from the
+    reference): every stage output of nine small proofs is frozen."""
+    import importlib.util
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("gen_digests", os.path.join(here, "golden", "gen_oracle_proof_digests.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    want = json.load(open(os.path.join(here, "golden", "oracle_proof_digests.json")))
+    for f, n, b, s in gen.CASES:
+        assert gen.digest_of(f, n, b, s) == want[f"{f}-{n}-{b}-{s}"], (f, n, b, s)
