@@ -38,14 +38,14 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--log-rows", type=int, default=20, help="log2 of trace rows (BASELINE configs[1]: 20)")
     ap.add_argument("--blowup", type=int, default=8)
     ap.add_argument("--field", type=int, default=0, help="0 Goldilocks, 1 BabyBear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-rows", type=int, default=18)
-    ap.add_argument("--inflight", type=int, default=4, help="independent proofs in flight per GPU (one ms_ctx + HIP stream each); a step = this many proofs")
+    ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (one ms_ctx + HIP stream each); a step = this many proofs")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="replicas (default): every rank proves its own traces, no data-path collective (weak scaling).  shard: ONE proof per step computed by all "
                          "ranks together (ms_set_shard: coset-partitioned LDE/FRI + leaf hashing, RCCL digest all-to-all and root all-gather; strong scaling)")
