@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--field", type=int, default=0, help="0 Goldilocks, 1 BabyBear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-rows", type=int, default=18)
-    ap.add_argument("--inflight", type=int, default=8, help="independent proofs in flight per GPU (one ms_ctx + HIP stream each); a step = this many proofs")
+    ap.add_argument("--inflight", type=int, default=None, help="independent proofs in flight per GPU (one ms_ctx + HIP stream each); a step = this many proofs (default: 8 up to 2^20 rows, fewer above)")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
                     help="replicas (default): every rank proves its own traces, no data-path collective (weak scaling).  shard: ONE proof per step computed by all "
                          "ranks together (ms_set_shard: coset-partitioned LDE/FRI + leaf hashing, RCCL digest all-to-all and root all-gather; strong scaling)")
@@ -70,6 +70,8 @@ def main():
     N = 1 << args.log_rows
     steps = N - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
     import threading
+    if args.inflight is None:  # 8 fills the 4 hardware queues twice over at the benchmark size; larger proofs need the HBM (25 GiB each at 2^24 rows)
+        args.inflight = 8 if args.log_rows <= 20 else (4 if args.log_rows == 21 else (3 if args.log_rows == 22 else 2))
     shard = args.mode == "shard" and world > 1
     C_IN = 1 if shard else max(1, args.inflight)
     # one context (own HIP stream, own HBM buffers) per in-flight proof; raises if libministark.so / the GPU is missing
