@@ -182,7 +182,11 @@ def main():
             pc.drive(orc.Session(args.field), args.field, tr, args.blowup, max(0, cfg.fri_queries - 2), seed=1, q_ood=cfg.constrain_queries, read_big=False)
             ct = time.perf_counter() - c0
             scale = float(1 << (args.log_rows - cl))
-            out["cpu_baseline"] = {"value": 1.0 / (ct * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
+            try:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except Exception:
+                cpu_model = "unknown"
+            out["cpu_baseline"] = {"value": 1.0 / (ct * scale), "unit": "proofs/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
                                    "sample": f"one 2^{cl}-row proof of the same AIR on the oracle (oracle/ministark_oracle.cpp, 1 thread) took {ct:.2f} s; "
                                              f"scaled linearly x{int(scale)} to 2^{args.log_rows} rows (optimistic for the CPU: ignores the log factor)"}
             # the same sample with OpenMP over the oracle's independent loops (columns, leaf groups, tree levels):
