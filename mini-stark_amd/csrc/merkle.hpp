@@ -164,14 +164,15 @@ MS_HD u32 drop_bytes(u32 hi, u32 lo, u32 l, u32 sel) {
 // `drain` is the only compression site (the 64-round compression is instantiated ONCE per kernel: inlining
 // it at every append made the kernel I-cache bound); after a block is compressed the leftover words move
 // down to the buffer start.  Between two drains at most 4*(NWORDS-17)-3 bytes may be appended.
-template <int NWORDS, int NT> struct ShaStream {
-  static_assert(NWORDS > 17 && NWORDS <= 32, "buffer = one block + slack");
+template <int NWORDS, int NT, int MAXW, bool LAZY> struct ShaStream {
+  static_assert(NWORDS >= 16 + MAXW + 1 && NWORDS <= 48, "buffer = one or two blocks + room for one element");
   Sha256 h;
   u32* buf;    // this thread's word 0
   u32 acc;     // the last four bytes appended (low byte = most recent)
   u32 total;   // bytes appended
-  u32 done;    // words compressed (multiple of 16) = stream index of buf[0]
-  MS_HD void init(u32* lds_words, int tid_) { h.init(); buf = lds_words + tid_; acc = 0; total = 0; done = 0; }
+  u32 done;    // words compressed (multiple of 16); before the final drain it is the stream index of buf[0]
+  u32 fbase;   // `done` when the final drain began (buf[0] stays put from then on)
+  MS_HD void init(u32* lds_words, int tid_) { h.init(); buf = lds_words + tid_; acc = 0; total = 0; done = 0; fbase = 0; }
   // append the first nbytes (1 <= nbytes <= 4*NW) bytes of W (big-endian, zero beyond nbytes);
   // last4 = the last four bytes of the stream after the append (only its low min(4, bytes so far) bytes matter)
   template <int NW> MS_HD void append_words(const u32 (&W)[NW], u32 nbytes, u32 last4) {
@@ -190,36 +191,63 @@ template <int NWORDS, int NT> struct ShaStream {
     const u32 l4 = nbytes >= 4 ? w : ((acc << (8 * nbytes)) | (w >> (32 - 8 * nbytes)));
     append_words<1>(W, nbytes, l4);
   }
-  // compress the complete block, if there is one (appends between drains are < 64 bytes: at most one).  With `final`
-  // (uniform over the workgroup; the caller has appended the 0x80 byte of a msg_bytes-byte message) the FIPS 180-4
-  // padding is applied on the fly: words past the 0x80 byte read as zero and the last block carries the bit length.
-  // When the length does not fit behind the message, the message ends with one more block that holds NO message
-  // bytes (zeros + length).  Few lanes of a wave need it (0.9 % of the Fibonacci LDE rows), so it is not compressed
-  // here: drain returns true and the caller hands the state to PadOnlyBlockKernel, which runs those lanes compacted.
-  MS_HD bool drain(bool final, u32 msg_bytes) {
-    u32 limit = total >> 2, valid_end = 0;
-    if (final) { valid_end = (total + 3) >> 2; limit = ((msg_bytes + 9 + 63) >> 6) << 4; }
-    const u32 pending = limit - done;
-    if (pending >= 16) {
-      u32 w[16];
+  MS_HD void begin_final() { fbase = done; }
+  // Compresses at most ONE block per call (the only compression site of the kernel).
+  // Before the final drain: the block at buf[0..16) once it is complete, after which the leftover moves down.  LAZY buffers
+  // hold two blocks and compress only when some lane of the wave runs out of room: the lanes of a wave cross block
+  // boundaries within an element or two of each other, and compressing "whenever any lane has a block" ran the 64 rounds
+  // ~1.4 times per block on wide rows (lpn = 128), mostly masked off.
+  // Final drain (uniform over the workgroup; the caller has appended the 0x80 byte of a msg_bytes-byte message and called
+  // begin_final): called until it stops returning MORE; the FIPS 180-4 padding is applied on the fly — words past the 0x80
+  // byte read as zero, the last block carries the bit length.  When the length does not fit behind the message, the message
+  // ends with one more block that holds NO message bytes (zeros + length).  Few lanes of a wave need it (0.9 % of the
+  // Fibonacci LDE rows, but 44 % of its waves), so it is not compressed here: DEFER tells the caller to hand the state to
+  // PadOnlyBlockKernel, which runs those lanes compacted.
+  enum { DONE = 0, MORE = 1, DEFER = 2 };
+  MS_HD int drain(bool final, u32 msg_bytes) {
+    if (!final) {
+      const u32 pending = (total >> 2) - done;
+      const bool go = LAZY ? msrt::wave_any(pending + (u32)MAXW + 1u > (u32)NWORDS) : true;
+      if (go && pending >= 16) {
+        u32 w[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) w[i] = buf[i * NT];
-      if (final) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = (done + i < valid_end) ? w[i] : 0u;
-        if (pending == 16) { w[14] = 0; w[15] = msg_bytes * 8u; }  // messages are far below 2^29 bytes
-      }
-      h.compress(w);
-      done += 16;
-      if (!final) {  // move the leftover down
+        for (int i = 0; i < 16; i++) w[i] = buf[i * NT];
+        h.compress(w);
+        done += 16;
         u32 t[NWORDS - 16];
 #pragma unroll
         for (int k = 0; k < NWORDS - 16; k++) t[k] = buf[(k + 16) * NT];
 #pragma unroll
         for (int k = 0; k < NWORDS - 16; k++) buf[k * NT] = t[k];
       }
+      return DONE;
     }
-    return final && pending == 32;
+    const u32 valid_end = (total + 3) >> 2, limit = ((msg_bytes + 9 + 63) >> 6) << 4;
+    if constexpr (!LAZY) {
+      // fewer than 16 words were pending: one block at buf[0..16), possibly followed by the pad-only block
+      const u32 pending = limit - done;
+      u32 w[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) w[i] = buf[i * NT];
+#pragma unroll
+      for (int i = 0; i < 16; i++) w[i] = (done + i < valid_end) ? w[i] : 0u;
+      if (pending == 16) { w[14] = 0; w[15] = msg_bytes * 8u; }  // messages are far below 2^29 bytes
+      h.compress(w);
+      done += 16;
+      return pending == 32 ? DEFER : DONE;
+    } else {
+      const bool last = limit - done == 16;
+      if (limit - 16 >= valid_end && last) return DEFER;   // only the pad-only block is left
+      u32 w[16];
+      const u32* blk = buf + (done - fbase) * NT;
+#pragma unroll
+      for (int i = 0; i < 16; i++) w[i] = (done + i < valid_end) ? blk[i * NT] : 0u;
+      if (last) { w[14] = 0; w[15] = msg_bytes * 8u; }
+      h.compress(w);
+      done += 16;
+      if (limit == done) return DONE;
+      return (limit - 16 >= valid_end && limit - done == 16) ? DEFER : MORE;
+    }
   }
 };
 
@@ -336,7 +364,7 @@ template <> struct Affix<4> {
 // (row-major trace: width=1,row_stride=1; column-major LDE: width=c,col_stride=L;
 //  FRI codeword: width=1, limb_stride=D).
 // One thread owns one digest and walks the base limbs of its group: affix, decimal, affix, drain.
-template <class F, int E> struct LeafHashKernel {
+template <class F, int E, bool LAZY = false> struct LeafHashKernel {
   typedef typename F::T T;
   static constexpr int THREADS = msmerkle::THREADS;
   struct Params {
@@ -347,8 +375,9 @@ template <class F, int E> struct LeafHashKernel {
     u32* ovf_count; u32* ovf; u32 ovf_cap;  // deferred pad-only blocks: OVF_LISTS counters, and lists of ovf_cap entries of OVF_WORDS words (group, message bits)
   };
   static constexpr int MAX_BYTES = F::MAX_DIGITS + Affix<E>::MAX_BYTES;  // appended between two drains
-  static constexpr int NWORDS = 16 + (3 + MAX_BYTES + 3) / 4 + 2;
-  typedef ShaStream<NWORDS, THREADS> Stream;
+  static constexpr int MAXW = (3 + MAX_BYTES + 3) / 4 + 1;               // words one iteration can touch past the write position
+  static constexpr int NWORDS = (LAZY ? 32 : 16) + MAXW + 1;
+  typedef ShaStream<NWORDS, THREADS, MAXW, LAZY> Stream;
   static MS_HD int nphases(const Params&) { return 1; }
   static MS_HD size_t lds_bytes() { return (size_t)NWORDS * THREADS * sizeof(u32); }
   static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char* lds) {
@@ -360,7 +389,7 @@ template <class F, int E> struct LeafHashKernel {
     const u32 nlimbs = p.lpn * (u32)E;
     u32 msg_bytes = 0;
     bool deferred = false;
-    for (u32 j = 0; j <= nlimbs; j++) {
+    for (u32 j = 0; LAZY || j <= nlimbs; j++) {
       if (j < nlimbs) {
         const u32 k = j & (u32)(E - 1);
         const T v = p.base[(size_t)col * p.col_stride + row * p.row_stride + (size_t)k * p.limb_stride];
@@ -368,11 +397,14 @@ template <class F, int E> struct LeafHashKernel {
         put_dec<F>(s, v, p.zero_as_empty);
         Affix<E>::after(s, k);
         if (k == (u32)(E - 1) && ++col == p.width) { col = 0; row++; }
-      } else {
+      } else if (j == nlimbs) {
         msg_bytes = s.total;
         s.append_small(0x80000000u, 1);
+        s.begin_final();
       }
-      deferred = s.drain(j == nlimbs, msg_bytes);  // the only compression site
+      const int st = s.drain(j >= nlimbs, msg_bytes);  // the only compression site
+      if constexpr (LAZY) { if (j >= nlimbs && st != Stream::MORE) { deferred = st == Stream::DEFER; break; } }
+      else deferred = st == Stream::DEFER;
     }
     const u32 list = (u32)bx % (u32)OVF_LISTS;
     const u32 slot = msrt::wave_alloc_slot(p.ovf_count + list, deferred);

@@ -97,6 +97,7 @@ template <class F> struct Ctx : CtxBase {
 
   int device = 0, zae = 1, trace_mont = 0;
   int lde_linear = 1;  // MS_LDE_LINEAR=0 disables the linear-provenance shortcut of lde_compute (A/B measurements)
+  int leaf_lazy_min = 16;  // MS_LEAF_LAZY_MIN: leaf groups of at least this many base limbs use the wave-synchronous two-block leaf kernel
   int fri_pointwise = 1;  // MS_FRI_POINTWISE=0: codewords of FRI rounds >= 1 by NTT of the round polynomial instead of the evaluation-domain fold
   msrt::Stream* own_stream = nullptr;
   msrt::Stream* stream = nullptr;
@@ -409,6 +410,13 @@ template <class F> struct Ctx : CtxBase {
     lp.width = width; lp.lpn = (u32)lpn; lp.zero_as_empty = zae; lp.ngroups = ngroups; lp.nodes = out;
     lp.ovf_count = reinterpret_cast<u32*>(counters); lp.ovf = d_ovf.as<u32>(); lp.ovf_cap = (u32)cap;
     next_bytes = (double)ngroups * (lpn * EL * sizeof(T) + 32);
+    if (lpn * EL >= (size_t)leaf_lazy_min) {  // long messages (wide rows): the two-block buffer that compresses wave-synchronously
+      typedef msmerkle::LeafHashKernel<F, EL, true> LK;
+      typename LK::Params ll;
+      ll.base = lp.base; ll.col_stride = lp.col_stride; ll.row_stride = lp.row_stride; ll.limb_stride = lp.limb_stride; ll.width = lp.width; ll.lpn = lp.lpn;
+      ll.zero_as_empty = lp.zero_as_empty; ll.ngroups = lp.ngroups; ll.nodes = lp.nodes; ll.ovf_count = lp.ovf_count; ll.ovf = lp.ovf; ll.ovf_cap = lp.ovf_cap;
+      CK(run<LK>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, LK::lds_bytes(), ll));
+    } else
     CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
     msmerkle::PadOnlyBlockKernel::Params pp{lp.ovf_count, lp.ovf, (u32)cap, out};
     const size_t used = nwg < lists ? nwg : lists, per_list = grid1(cap, msmerkle::THREADS);
@@ -512,6 +520,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
+    if (const char* e = getenv("MS_LEAF_LAZY_MIN")) leaf_lazy_min = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MIN")) ntt_fast_min = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
     if (const char* e = getenv("MS_SHARD_MIN_LEAVES")) { long v = atol(e); if (v >= 1) shard_min_leaves = (size_t)v; }

@@ -59,6 +59,8 @@ MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { if (v 
 MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { unsigned o = *a; *a = o + v; return o; }
 // one slot of a device list per lane that wants one (call from all live lanes)
 MS_DEV unsigned wave_alloc_slot(unsigned* counter, bool want) { if (!want) return 0; unsigned o = *counter; *counter = o + 1; return o; }
+// true if the predicate holds on any live lane of the wave (emulation: a wave of one lane — results must not depend on it)
+MS_DEV bool wave_any(bool pred) { return pred; }
 }  // namespace msrt
 MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 
@@ -113,6 +115,8 @@ inline int launch(Stream* s, unsigned gx, unsigned gy, int threads, size_t lds_b
 MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { atomicMin(a, v); }
 MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { atomicMax(a, v); }
 MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { return atomicAdd(a, v); }
+// true if the predicate holds on any live lane of the wave
+MS_DEV bool wave_any(bool pred) { return __any(pred) != 0; }
 // one slot of a device list per lane that wants one (call from all live lanes): ONE atomic per wave, not per lane
 MS_DEV unsigned wave_alloc_slot(unsigned* counter, bool want) {
   const unsigned long long mask = __ballot(want);
