@@ -10,10 +10,12 @@
 // "QuadExtField(c0 + c1 * u)" (nested) for the extension towers.
 //
 // One thread owns one digest.  An element becomes 4-digit decimal chunks packed as
-// big-endian ASCII words (no per-digit work), appended through a 64-bit funnel
-// into a per-thread ring of message words that lives in LDS word-interleaved
-// across the workgroup (bank-conflict free); complete 64-byte blocks are
-// compressed with SHA-256 state and schedule in registers.  Both passes are
+// big-endian ASCII words (no per-digit work), shifted into place by funnel shifts
+// and stored into a per-thread buffer of message words (one or two blocks + slack)
+// that lives in LDS word-interleaved across the workgroup (bank-conflict free);
+// complete 64-byte blocks are compressed with SHA-256 state and schedule in
+// registers; final blocks without message bytes are finished by a compacted
+// follow-up kernel (PadOnlyBlockKernel).  Both passes are
 // integer-VALU-issue bound, not HBM bound: algorithmic traffic is
 // lpn*E*sizeof(T) + 32 bytes per leaf group and 96 bytes per inner node against
 // 2-3 compressions (~1440 instructions each).
