@@ -94,6 +94,37 @@ class StarkProof:  # src/starks.rs:21-28
     fri_proof: FriProof
     fri_roots: List[bytes] = _field(default_factory=list)
 
+    # ---- wire format "MSSP" (build-defined: the reference derives no Serialize for StarkProof/FriProof/MerklePath)
+    #   u32 magic 'MSSP' | u32 version 1 | u32 E | u32 c | u32 q | u32 rounds | u64 len(arthur) | u64 len(fri blob)
+    #   trace_commit[32] | constrain_trace_commit[32] | constrain_queries q*c*E u64 | validity_queries q*E u64
+    #   fri_roots rounds*32 (round 0 first; not part of the reference's StarkProof: round 0's root never reaches the transcript)
+    #   arthur bytes | FriProof in the MSFP layout of include/ministark.h            (all little-endian)
+    def to_bytes(self) -> bytes:
+        cq = np.ascontiguousarray(self.constrain_queries, dtype="<u8")
+        vq = np.ascontiguousarray(self.validity_queries, dtype="<u8")
+        q, c, e = cq.shape
+        if self.fri_proof.device_resident:
+            raise ValueError("the FRI proof was left in HBM (read_fri_proof=False): nothing to serialise")
+        head = struct.pack("<4sIIIIIQQ", b"MSSP", 1, e, c, q, len(self.fri_roots), len(self.arthur), len(self.fri_proof.blob))
+        return b"".join([head, self.trace_commit, self.constrain_trace_commit, cq.tobytes(), vq.tobytes(), b"".join(self.fri_roots), self.arthur, self.fri_proof.blob])
+
+    @staticmethod
+    def from_bytes(data: bytes) -> "StarkProof":
+        hs = struct.calcsize("<4sIIIIIQQ")
+        magic, ver, e, c, q, rounds, la, lb = struct.unpack_from("<4sIIIIIQQ", data, 0)
+        if magic != b"MSSP" or ver != 1:
+            raise ValueError("not an MSSP v1 proof")
+        need = hs + 64 + 8 * q * (c + 1) * e + 32 * rounds + la + lb
+        if len(data) != need:
+            raise ValueError(f"MSSP proof has {len(data)} bytes, header says {need}")
+        pos = hs
+        tc, lc = data[pos:pos + 32], data[pos + 32:pos + 64]; pos += 64
+        cq = np.frombuffer(data, dtype="<u8", count=q * c * e, offset=pos).reshape(q, c, e).copy(); pos += 8 * q * c * e
+        vq = np.frombuffer(data, dtype="<u8", count=q * e, offset=pos).reshape(q, e).copy(); pos += 8 * q * e
+        roots = [data[pos + 32 * i:pos + 32 * i + 32] for i in range(rounds)]; pos += 32 * rounds
+        arthur = data[pos:pos + la]; pos += la
+        return StarkProof(arthur, tc, lc, cq, vq, FriProof(data[pos:pos + lb], device_resident=False), roots)
+
 
 class StarkConfig:
     """src/starks.rs:238-333."""

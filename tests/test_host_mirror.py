@@ -146,3 +146,22 @@ def test_prove_then_verify_roundtrip(emu, field, steps, blowup):
     # round 0's root is NOT bound by the transcript (fri.rs:73-82 never sends it): a wrong root0 is only caught by the Merkle paths
     bad = copy.deepcopy(proof); r = bytearray(proof.fri_roots[0]); r[0] ^= 1; bad.fri_roots = [bytes(r)] + proof.fri_roots[1:]
     assert "Merkle" in rejected(bad)
+
+
+@pytest.mark.parametrize("field,steps", [(0, 63), (1, 31)])
+def test_proof_wire_format_roundtrip(emu, field, steps):
+    """StarkProof.to_bytes / from_bytes ("MSSP", mini-stark_amd/stark.py): the deserialised proof verifies, truncation is refused."""
+    from mini_stark_amd.stark import StarkProof
+    ctx = ms.Context(field, lib_path=emu)
+    tt = fibonacci_air(ctx, steps)
+    hs = HostStark(ctx, 20, 8, steps, tt.constrain_number())
+    constrains = hs.derive_constrains(tt)
+    proof = hs.prove(tt)
+    wire = proof.to_bytes()
+    back = StarkProof.from_bytes(wire)
+    assert back.to_bytes() == wire and back.fri_roots == proof.fri_roots and back.fri_proof.blob == proof.fri_proof.blob
+    assert hs.verify(constrains, back), hs.last_verify_error
+    with pytest.raises(ValueError):
+        StarkProof.from_bytes(wire[:-1])
+    with pytest.raises(ValueError):
+        StarkProof.from_bytes(b"XXXX" + wire[4:])
