@@ -97,6 +97,7 @@ template <class F> struct Ctx : CtxBase {
 
   int device = 0, zae = 1, trace_mont = 0;
   int lde_linear = 1;  // MS_LDE_LINEAR=0 disables the linear-provenance shortcut of lde_compute (A/B measurements)
+  int tree_top_parents = msmerkle::THREADS;  // MS_TREE_TOP: levels of at most this many parents are walked by one workgroup in one launch (measured: 256 beats 1024 by 3 % in latency)
   int leaf_lazy_min = 16;  // MS_LEAF_LAZY_MIN: leaf groups of at least this many base limbs use the wave-synchronous two-block leaf kernel
   int fri_pointwise = 1;  // MS_FRI_POINTWISE=0: codewords of FRI rounds >= 1 by NTT of the round polynomial instead of the evaluation-domain fold
   msrt::Stream* own_stream = nullptr;
@@ -438,7 +439,7 @@ template <class F> struct Ctx : CtxBase {
       msmerkle::InnerHashKernel::Params ip;
       ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic;
       const size_t nparents = nchildren / ic;
-      if (nparents <= 4 * (size_t)msmerkle::THREADS) {  // fused tree top: one workgroup walks the remaining levels
+      if (nparents <= (size_t)tree_top_parents) {  // fused tree top: one workgroup walks the remaining levels
         u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ic) nl++;
         ip.nlevels = nl;
         next_bytes = (double)nchildren * 32 * 2;
@@ -521,6 +522,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
     if (const char* e = getenv("MS_LEAF_LAZY_MIN")) leaf_lazy_min = atoi(e);
+    if (const char* e = getenv("MS_TREE_TOP")) { int v = atoi(e); if (v >= 1 && v <= 65536) tree_top_parents = v; }
     if (const char* e = getenv("MS_NTT_FAST_MIN")) ntt_fast_min = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
     if (const char* e = getenv("MS_SHARD_MIN_LEAVES")) { long v = atol(e); if (v >= 1) shard_min_leaves = (size_t)v; }
