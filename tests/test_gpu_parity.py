@@ -144,10 +144,16 @@ def test_host_mirror_on_gpu(mk, field, steps, blowup):
     thm.check_pair(mk(field), steps, blowup)
 
 
-def test_full_size_bit_exact_vs_oracle(mk):
-    """BASELINE.json configs[1] at full size (2^20 rows, blowup 8, Goldilocks): every commitment, OOD value, FRI round
-    and the serialised FRI proof (~64 MiB) bit-exact against the single-threaded CPU oracle (~1 min of host time)."""
-    pc.case_prove(mk, 0, 20, 8, nq_fri=0, read_big=False)
+@pytest.mark.parametrize("field,log_n", [(0, 20), (1, 20), (0, 22)])
+def test_full_size_bit_exact_vs_oracle(mk, field, log_n):
+    """BASELINE.json configs[1] and configs[2] at full size (2^20 rows, blowup 8, Goldilocks / BabyBear+Fp4) and a 2^22-row proof: every
+    commitment, OOD value, FRI round and the serialised FRI proof (64-256 MiB) bit-exact against the CPU oracle (OpenMP over its
+    independent loops, <= 16 threads).  The 2^24-row proof of configs[3] was checked the same way once (tools/fullsize_parity.py, 164 s)."""
+    orc.set_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    try:
+        pc.case_prove(mk, field, log_n, 8, nq_fri=0, read_big=False)
+    finally:
+        orc.set_threads(1)
 
 
 def test_full_size_ood_values_verify(mk):
