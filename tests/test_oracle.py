@@ -290,3 +290,18 @@ def test_oracle_matches_committed_proof_digests():
     want = json.load(open(os.path.join(here, "golden", "oracle_proof_digests.json")))
     for f, n, b, s in gen.CASES:
         assert gen.digest_of(f, n, b, s) == want[f"{f}-{n}-{b}-{s}"], (f, n, b, s)
+
+
+def test_oracle_openmp_matches_single_thread():
+    """or_set_threads only changes how the oracle's independent loops are scheduled: same bytes out."""
+    import parity_cases as pc
+    from common import fibonacci_trace_fast
+    for field, log_n in ((0, 13), (1, 12)):
+        tr = fibonacci_trace_fast(field, 1 << log_n)
+        one = pc.drive(orc.Session(field), field, tr, 8, 1, seed=4, read_big=False)
+        orc.set_threads(4)
+        try:
+            many = pc.drive(orc.Session(field), field, tr, 8, 1, seed=4, read_big=False)
+        finally:
+            orc.set_threads(1)
+        assert one == many
