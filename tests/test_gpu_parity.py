@@ -182,6 +182,16 @@ def test_wide_air_shape(mk, field):
     pc.case_prove_wide(mk, field, log_n=10, w=64)
 
 
+def test_wide_air_2p18_vs_oracle(mk):
+    """BASELINE configs[4] shape (64 trace columns, c = 128) at 2^18 rows, bit-exact vs the oracle; the full 2^22-row instance was
+    checked once with tools/fullsize_parity.py (167 s)."""
+    orc.set_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    try:
+        pc.case_prove_wide(mk, 0, log_n=18, w=64)
+    finally:
+        orc.set_threads(1)
+
+
 @pytest.mark.parametrize("field", [0, 1])
 def test_general_closure_path(mk, field):
     pc.case_general_closure(mk, field)
