@@ -96,7 +96,8 @@ uint64_t ms_root_of_unity(ms_field f, uint64_t n); /* Radix2EvaluationDomain::ne
 /* 1.1  MerkleTree::new(trace.get_data(), lpn) -> root.  starks.rs:68-73, air.rs:15-59.
  *      `trace` is the N x w row-major matrix (N a power of two).  Also uploads the trace. */
 int ms_trace_commit(ms_ctx* ctx, const uint64_t* trace_rowmajor, size_t N, size_t w, size_t lpn, uint8_t root[32]);
-/*      Same, for a trace already resident in HBM (device pointer, same layout). */
+/*      Same, for a trace already resident in HBM (device pointer, same layout).  Elements must be canonical (< p) like the
+ *      host path's; the range check runs inside the transposing kernel and the call returns MS_ERR_ARG if any element is >= p. */
 int ms_trace_commit_device(ms_ctx* ctx, const void* d_trace_rowmajor, size_t N, size_t w, size_t lpn, uint8_t root[32]);
 /* 1.2a TraceTable::get_trace_polys: per-column INTT.  air.rs:147-160. */
 int ms_interpolate(ms_ctx* ctx);

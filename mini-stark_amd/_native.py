@@ -46,7 +46,7 @@ def build_library(force=False):
 
 
 def load_library(path=None):
-    path = path or os.environ.get("MS_LIB") or library_path()  # MS_LIB: tuning builds of the same HIP library (tools/*_exp.sh)
+    path = path or library_path()   # the product loads its own in-tree HIP build only (tests pass the emulation build explicitly)
     if path in _LIBS:
         return _LIBS[path]
     if not os.path.exists(path):

@@ -589,12 +589,16 @@ template <class F> struct Ctx : CtxBase {
     RQ(ensure_polys(w + 1));
     // 2^-64 mod p: arkworks stores Montgomery representatives (R = 2^64 for the one-limb Fp of both fields)
     const T rinv = f_inv<F>(F::from_u64((u64)(((unsigned __int128)1 << 64) % F::P)));
-    typename mspoly::TransposeInKernel<F>::Params tp{dsrc, d_polys.as<T>(), N, w, N, rinv, trace_mont};
+    void* badw;
+    RQ(zero_alloc(4, &badw));  // device input cannot be range-checked on the host: the kernel flags elements >= p
+    typename mspoly::TransposeInKernel<F>::Params tp{dsrc, d_polys.as<T>(), N, w, N, rinv, trace_mont, reinterpret_cast<u32*>(badw)};
     CK(run<mspoly::TransposeInKernel<F>>(K_TRANSPOSE, grid1(N * w, mspoly::THREADS), 1, mspoly::THREADS, 0, tp));
     // element f of trace.get_data() = column f % w, row f / w of the column-major copy
     RQ((tree_build<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
     trace_ts = ts;
+    CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 128, badw, 4, stream));
     RQ(read_root(d_trace_nodes, ts, root));
+    if (*reinterpret_cast<const u32*>(reinterpret_cast<const u8*>(pinned) + 128)) return fail(MS_ERR_ARG, "trace element not canonical (>= p)");
     have_trace = true;
     return MS_OK;
   }
@@ -637,12 +641,12 @@ template <class F> struct Ctx : CtxBase {
   // ------------------------------------------------------------------ starks.rs:80-95
   // one lincomb launch chain: dst = sum_t s[t] * base[idx[t]] over n elements (columns `stride` apart)
   int lincomb_into(const T* base, size_t stride, size_t n, const u64* sc, const int* idx, int k, int self_index, T* dst) {
-    for (int t0 = 0; t0 < k; t0 += mspoly::MAX_TERMS - 1) {
+    for (int t = 0; t < k;) {  // MAX_TERMS terms per launch; launches after the first spend one slot on the partial result
       typename mspoly::LincombKernel<F>::Params p;
       p.polys = base; p.stride = stride; p.n = n; p.dst = dst;
       int kk = 0;
-      if (t0 > 0) { p.s[kk] = F::from_u64(1); p.idx[kk] = self_index; kk++; }  // accumulate onto the partial result
-      for (int t = t0; t < k && kk < mspoly::MAX_TERMS; t++, kk++) { p.s[kk] = F::from_u64(sc[t]); p.idx[kk] = idx[t]; }
+      if (t > 0) { p.s[kk] = F::from_u64(1); p.idx[kk] = self_index; kk++; }  // accumulate onto the partial result
+      for (; t < k && kk < mspoly::MAX_TERMS; t++, kk++) { p.s[kk] = F::from_u64(sc[t]); p.idx[kk] = idx[t]; }
       p.k = kk;
       CK(run<mspoly::LincombKernel<F>>(K_LINCOMB, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
     }
@@ -1257,7 +1261,7 @@ template <class F> struct Ctx : CtxBase {
     if (ds.ensure(leaf_num * EL * sizeof(T)) || dw.ensure(off_path + plen) || d_io.ensure(leaf_num * EL * 8)) rc = fail(MS_ERR_NOMEM, "merkle_prove");
     if (!rc) {
       int e = msrt::h2d(d_io.p, leafs, leaf_num * EL * 8, stream);
-      typename mspoly::TransposeInKernel<F>::Params tp{d_io.as<u64>(), ds.as<T>(), leaf_num, (size_t)EL, leaf_num, F::from_u64(1), 0};
+      typename mspoly::TransposeInKernel<F>::Params tp{d_io.as<u64>(), ds.as<T>(), leaf_num, (size_t)EL, leaf_num, F::from_u64(1), 0, nullptr};
       if (!e) e = run<mspoly::TransposeInKernel<F>>(K_TRANSPOSE, grid1(leaf_num * EL, mspoly::THREADS), 1, mspoly::THREADS, 0, tp);
       if (e) rc = fail_rt(e, "leaf upload");
     }
@@ -1364,6 +1368,8 @@ int ms_num_queries(ms_field f, uint64_t security_bits, uint64_t blowup, uint64_t
   if (security_bits < 20) return MS_ERR_SHAPE;  // starks.rs:317-320 panics
   const u64 modulus_bits = (f == MS_FIELD_GOLDILOCKS) ? 64 : 31;
   const u64 log_steps = ceil_log2_k(steps, 2);
+  if (log_steps >= modulus_bits) return MS_ERR_SHAPE;          // starks.rs:322 would divide by zero / underflow (panics)
+  if (steps > ~(u64)0 / blowup) return MS_ERR_SHAPE;           // steps * blowup overflows u64 (starks.rs:277 panics in debug)
   const u64 den = modulus_bits - log_steps;
   *linking = (security_bits + den - 1) / den;
   const u64 rounds = ceil_log2_k(steps * blowup, 2);

@@ -23,13 +23,17 @@ constexpr int THREADS = 256;
 template <class F> struct TransposeInKernel {
   typedef typename F::T T;
   static constexpr int THREADS = mspoly::THREADS;
-  struct Params { const u64* src; T* dst; size_t N, w, dst_stride; T rinv; int mont; /* mont: src holds x*2^64 mod p; rinv = 2^-64 mod p */ };
+  // bad: optional device word (zeroed by the caller) set to 1 when an input element is not canonical (>= p)
+  struct Params { const u64* src; T* dst; size_t N, w, dst_stride; T rinv; int mont; /* mont: src holds x*2^64 mod p; rinv = 2^-64 mod p */ u32* bad; };
   static MS_HD int nphases(const Params&) { return 1; }
   static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
     const size_t f = (size_t)bx * nthreads + tid;
     if (f >= p.N * p.w) return;
     const size_t row = f / p.w, col = f - row * p.w;
-    T v = F::from_u64(p.src[f]);
+    const u64 raw = p.src[f];
+    const bool oob = raw >= F::P;
+    if (oob && p.bad) *p.bad = 1;            // racing writers all store the same value; the call then fails with MS_ERR_ARG
+    T v = F::from_u64(oob ? 0 : raw);
     if (p.mont) v = F::mul(v, p.rinv);
     p.dst[col * p.dst_stride + row] = v;
   }

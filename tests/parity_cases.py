@@ -199,6 +199,9 @@ def case_errors(mk, field):
     assert ctx.merkle_commit(np.zeros(0, dtype=np.uint64), 1, 2, 2)[0] == ms.ERR_SHAPE
     assert ctx.num_queries(1, 4, 128)[0] == ms.ERR_SHAPE          # starks.rs:341-346
     assert ctx.num_queries(20, 4, 129) == (0, 1, 3) if field == 0 else True
+    # the reference panics (division by zero / overflow) where these used to SIGFPE or wrap across the C ABI
+    assert ctx.num_queries(20, 4, 2**63 if field == 1 else 2**64 - 1)[0] == ms.ERR_SHAPE   # log_steps >= modulus_bits
+    assert ctx.num_queries(20, 2**40, 2**30)[0] == ms.ERR_SHAPE                              # steps * blowup overflows u64
 
 
 def case_prove_wide(mk, field, log_n=8, w=64, blowup=8, seed=5):
@@ -282,3 +285,54 @@ def case_merkle_prove(mk, field, leaf_num=64, ext=1, lpn=2):
     missing = (leafs[0] + np.uint64(1)) % np.uint64(MODULUS[field])
     if not (leafs == missing).all(axis=1).any():
         assert ctx.merkle_prove(flat, missing, ext, lpn)[0] == ms.ERR_LEAF_NOT_FOUND
+
+
+def case_lincomb_many_terms(mk_fresh, field, k, linear, log_n=5, blowup=4):
+    """ms_polys_lincomb with k terms (k >= MAX_TERMS = 8 needs several kernel launches chained through the partial result):
+    the constraint polynomial AND its LDE column, with the linear-provenance shortcut on (MS_LDE_LINEAR=1) and off (0), against the
+    oracle.  `mk_fresh(field)` must create a NEW context (the knob is read at ms_create)."""
+    import os
+    p = MODULUS[field]
+    N = 1 << log_n
+    w = 4
+    trace = rand_field(field, (N, w), seed=1000 + k)
+    rng = SplitMix64(500 + k)
+    sc = [rng.nonzero(p) for _ in range(k)]
+    idx = [int(rng.next() % w) for _ in range(k)]
+    old = os.environ.get("MS_LDE_LINEAR")
+    os.environ["MS_LDE_LINEAR"] = str(linear)
+    try:
+        ctx = mk_fresh(field)
+    finally:
+        if old is None:
+            del os.environ["MS_LDE_LINEAR"]
+        else:
+            os.environ["MS_LDE_LINEAR"] = old
+    o = orc.Session(field)
+    lpn = 2 * (w + 2)
+    for s in (ctx, o):
+        assert s.trace_commit(trace, w)[0] == 0 and s.interpolate() == 0
+        assert s.polys_lincomb(sc, idx) == 0
+        assert s.polys_lincomb(sc[::-1] + [1], idx[::-1] + [w]) == 0   # a second one that also combines the first combination
+    for i in (w, w + 1):
+        assert (ctx.poly_read(i) == o.poly_read(i)).all(), f"constraint polynomial {i} with k={k} differs"
+    ra, rb = ctx.lde_commit(blowup, 7, w + 2), o.lde_commit(blowup, 7, w + 2)
+    assert ra[0] == 0 and rb[0] == 0 and ra[1] == rb[1]
+    assert (ctx.lde_read() == o.lde_read()).all()
+
+
+def case_device_trace_range_check(mk, field, to_device):
+    """ms_trace_commit_device validates the canonical range on the device: a trace element >= p gives MS_ERR_ARG, like
+    the host path; a clean trace gives the host path's root.  `to_device(np_u64_array) -> (pointer, keepalive)`."""
+    import mini_stark_amd as ms
+    ctx = mk(field, fresh=True)
+    t = fibonacci_trace(field, 16)
+    rc_h, root_h = ctx.trace_commit(t, 6)
+    ptr, keep = to_device(np.ascontiguousarray(t))
+    rc_d, root_d = ctx.trace_commit_device(ptr, 16, 3, 6)
+    assert rc_h == 0 and rc_d == 0 and root_h == root_d
+    bad = t.copy(); bad[5, 1] = MODULUS[field] + 3
+    ptr, keep2 = to_device(np.ascontiguousarray(bad))
+    assert ctx.trace_commit_device(ptr, 16, 3, 6)[0] == ms.ERR_ARG
+    assert ctx.interpolate() == ms.ERR_STATE      # the failed commit left no trace behind
+    del keep, keep2

@@ -140,3 +140,15 @@ def test_prove_randomised_shapes(mk):
 @pytest.mark.parametrize("field,ext,lpn,n", [(0, 1, 2, 64), (0, 1, 4, 64), (0, 2, 2, 32), (1, 4, 2, 16), (1, 1, 8, 4096)])
 def test_merkle_prove_by_value(mk, field, ext, lpn, n):
     pc.case_merkle_prove(mk, field, n, ext, lpn)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("k", [7, 8, 9, 15, 16])
+@pytest.mark.parametrize("linear", [0, 1])
+def test_lincomb_many_terms(mk, field, k, linear):
+    pc.case_lincomb_many_terms(lambda f: mk(f, fresh=True), field, k, linear)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_device_trace_range_check(mk, field):
+    pc.case_device_trace_range_check(mk, field, lambda a: (a.ctypes.data, a))   # emulation: "device" memory is host memory

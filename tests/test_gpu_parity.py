@@ -253,3 +253,49 @@ def test_sharded_full_size_matches_unsharded():
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     calls = {int(k): v for k, v in res["calls"].items()}
     assert calls[0] == 9 and calls[1] == 9 and calls[2] == 1 and calls[3] == 1
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("k", [7, 8, 9, 15, 16])
+@pytest.mark.parametrize("linear", [0, 1])
+def test_lincomb_many_terms(mk, field, k, linear):
+    pc.case_lincomb_many_terms(lambda f: mk(f, fresh=True), field, k, linear)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_device_trace_range_check(mk, field):
+    import torch
+
+    def to_device(a):
+        t = torch.from_numpy(a.view(np.int64)).to("cuda:0")
+        torch.cuda.synchronize()
+        return t.data_ptr(), t
+    pc.case_device_trace_range_check(mk, field, to_device)
+
+
+@pytest.mark.parametrize("field,log_n", [(0, 10), (1, 10), (0, 16)])
+def test_mont64_trace_input_on_gpu(mk, field, log_n):
+    """MS_FLAG_TRACE_MONT64 on the HIP build (the flag INTEGRATION.md tells the Rust shim to use: arkworks keeps Fp as x * 2^64 mod p):
+    a Montgomery-form trace, host and device-resident, gives the canonical trace's proof bit for bit."""
+    import torch
+    from mini_stark_amd.host import HostStark, build_host_library
+    from mini_stark_amd.stark import fibonacci_air
+    build_host_library()
+    p = MODULUS[field]
+    steps = (1 << log_n) - 1
+    ctx = mk(field)
+    tt = fibonacci_air(ctx, steps)
+    proof = HostStark(ctx, 20, 8, steps, tt.constrain_number()).prove(tt)
+    mctx = ms.Context(field, flags=ms.FLAG_ZERO_DISPLAY_EMPTY | ms.FLAG_TRACE_MONT64)
+    mt = fibonacci_air(mctx, steps)
+    R = (1 << 64) % p
+    mt.data[:] = np.array([int(v) * R % p for v in tt.data.reshape(-1)], dtype=np.uint64).reshape(tt.data.shape)
+    hs = HostStark(mctx, 20, 8, steps, mt.constrain_number())
+    mp = hs.prove(mt)
+    assert mp.arthur == proof.arthur and mp.fri_proof.blob == proof.fri_proof.blob and mp.trace_commit == proof.trace_commit
+    d = torch.from_numpy(mt.data.view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    mctx.check(hs.prove_raw(mt, trace_device_ptr=d.data_ptr(), read_fri_proof=True))
+    dp = hs.last_proof(read_fri_proof=True)
+    assert dp.arthur == proof.arthur and dp.fri_proof.blob == proof.fri_proof.blob and dp.constrain_trace_commit == proof.constrain_trace_commit
+    mctx.close()

@@ -11,5 +11,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 ben
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline > $O/pmc_sq.log 2>&1
-./tools/valu_rate > $O/valu_rate.txt 2>&1 || true
+hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate > $O/valu_rate.txt 2>&1 || true   # built from source every time (the binary is not tracked)
 ls $O
