@@ -30,6 +30,8 @@ else:
     ctx = ms.Context(field, lib_path=os.environ.get("MS_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "libministark_emu.so"))  # MS_EMU_LIB: sanitizer builds
     xchg = ShardExchange(grp, ctx, cap)
 trace = fibonacci_trace_fast(field, N)
+if log_n >= 16:  # full-size comparisons: OpenMP over the oracle's independent loops (every rank runs its own oracle)
+    orc.set_threads(max(1, min(8, len(os.sched_getaffinity(0)) // grp.world)))
 got = pc.drive(ctx, field, trace, blowup, 2, seed=11, read_big=False)
 if self_check:
     want = pc.drive(ms.Context(field), field, trace, blowup, 2, seed=11, read_big=False)

@@ -239,15 +239,16 @@ def test_prove_then_verify_roundtrip_on_gpu(mk, field, log_n):
     assert not hs.verify(constrains, proof) and "linearity" in hs.last_verify_error
 
 
-def test_sharded_full_size_matches_unsharded():
+def test_sharded_full_size_matches_oracle():
     """BASELINE configs[1] size (2^20 rows, blowup 8) proved by 2 ranks sharing the GPU (default MS_SHARD_MIN_LEAVES: the LDE and the
-    eight largest FRI rounds are sharded): every commitment, DEEP value and the 64 MiB FRI proof equal the unsharded proof's."""
+    eight largest FRI rounds are sharded): every commitment, DEEP value and the 64 MiB FRI proof equal the CPU ORACLE's (each rank runs
+    the oracle itself, OpenMP x8)."""
     import json
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29961", os.path.join(here, "shard_worker.py"), "0", "20", "8", "32768", "gpu-self"]
+           "--master-port", "29961", os.path.join(here, "shard_worker.py"), "0", "20", "8", "32768", "gpu"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -299,3 +300,35 @@ def test_mont64_trace_input_on_gpu(mk, field, log_n):
     dp = hs.last_proof(read_fri_proof=True)
     assert dp.arthur == proof.arthur and dp.fri_proof.blob == proof.fri_proof.blob and dp.constrain_trace_commit == proof.constrain_trace_commit
     mctx.close()
+
+
+def _oracle_threads():
+    return max(1, min(64, len(os.sched_getaffinity(0))))
+
+
+def test_config3_2p24_rows_bit_exact_vs_oracle(mk):
+    """BASELINE.json configs[3] at FULL size on one GPU: Fibonacci AIR, Goldilocks, 2^24 trace rows, blowup 8 (L = 2^27, 27 FRI rounds,
+    ~25 GiB resident): every commitment, DEEP value, FRI round and the ~1 GiB serialised FRI proof bit-exact against the CPU oracle
+    (OpenMP over its independent loops).  Minutes of host time; the log of the builder's run is profiles/r02_fullsize_parity.log."""
+    import time
+    orc.set_threads(_oracle_threads())
+    t0 = time.time()
+    try:
+        pc.case_prove(mk, 0, 24, 8, nq_fri=0, read_big=False)
+    finally:
+        orc.set_threads(1)
+    print(f"configs[3] 2^24 rows Goldilocks: bit-exact vs oracle in {time.time() - t0:.0f} s ({_oracle_threads()} oracle threads)")
+
+
+def test_config4_wide_air_2p22_rows_bit_exact_vs_oracle(mk):
+    """BASELINE.json configs[4] at FULL size on one GPU: wide AIR, 64 trace columns + 64 transition polynomials (c = 128), Goldilocks,
+    2^22 rows, blowup 8 (32 GiB LDE matrix, 2.5 KB leaf messages): bit-exact against the CPU oracle.  The transition polynomials are
+    linear: degree-3 constraints are not expressible in the reference (quirk Q1)."""
+    import time
+    orc.set_threads(_oracle_threads())
+    t0 = time.time()
+    try:
+        pc.case_prove_wide(mk, 0, log_n=22, w=64)
+    finally:
+        orc.set_threads(1)
+    print(f"configs[4] wide AIR 2^22 rows: bit-exact vs oracle in {time.time() - t0:.0f} s ({_oracle_threads()} oracle threads)")
