@@ -25,26 +25,45 @@ struct GL {
   static constexpr int EXT = 2;  // StarkField::Extension = GoldilocksFp2 (field.rs:38-41)
   static constexpr u64 NR2 = 7;
   static constexpr int MAX_DIGITS = 20;
+  // All operations take and return canonical values (< P).  They are written without compares / selects on purpose: on gfx950 a
+  // v_cmp_*_u64 + v_cndmask pair costs ~9 issue cycles and a trip through an SGPR pair, while the same decision made on the sign
+  // bits of the high words is one v_bitop3_b32 (2.7 cycles) and one arithmetic shift (rt.hpp: ms_bitop3 / ms_sar31).
+  static MS_HD u32 hi(u64 x) { return (u32)(x >> 32); }
+  static MS_HD u32 lo(u64 x) { return (u32)x; }
+  static MS_HD u64 mk(u32 l, u32 h) { return ((u64)h << 32) | l; }
+  static MS_HD u64 sel(u32 m, u64 t, u64 s) { return mk(ms_bitop3<0xCA>(m, lo(t), lo(s)), ms_bitop3<0xCA>(m, hi(t), hi(s))); }  // m ? t : s (m = 0 / ~0)
   static MS_HD T add(T a, T b) {
-    const T s = a + b;
-    const T t = s - P;           // also the wrapped case: s + 2^64 - p == s - p (mod 2^64)
-    return (s < a || s >= P) ? t : s;
+    const u64 s = a + b, t = s + EPS;                              // t = s - P (mod 2^64)
+    const u32 c1 = ms_bitop3<0xD4>(hi(a), hi(b), hi(s));           // bit 31: carry out of a + b = maj(a, b, ~s)
+    const u32 m = ms_sar31(ms_bitop3<0xF4>(c1, hi(s), hi(t)));     // ... or s >= P, i.e. carry out of s + EPS = s & ~t
+    return sel(m, t, s);
   }
   static MS_HD T sub(T a, T b) {
-    T d = a - b;
-    if (a < b) d -= EPS;         // wrapped: - 2^64 == - EPS (mod p)
-    return d;
+    const u64 d = a - b;
+    const u32 bo = ms_bitop3<0x8E>(hi(a), hi(b), hi(d));           // bit 31: borrow out of a - b
+    return d + ms_pin64(mk(bo >> 31, ms_sar31(bo)));               // + P on a borrow
   }
   static MS_HD T neg(T a) { return a ? P - a : 0; }
-  // 128-bit product folded with 2^64 == 2^32 - 1 and 2^96 == -1 (mod p)
-  static MS_HD T reduce128(u64 lo, u64 hi) {
-    const u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
-    u64 t0 = lo - hi_hi;
-    t0 -= (lo < hi_hi) ? EPS : 0;          // borrow: - 2^64 == - EPS
-    const u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * EPS
-    const u64 r = t0 + t1;
-    const u64 r2 = r + EPS;                // r - p (mod 2^64): the fix for a carry AND for p <= r < 2^64
-    return (r < t1 || r >= P) ? r2 : r;
+  // A + h * 2^64 for h < 2^31  (2^64 == EPS): one multiply-add, the wrap / >= P decision on sign bits
+  static MS_HD T fold_small(u64 A, u32 h) {
+    const u64 r = (u64)h * 0xFFFFFFFFu + A, t = r + EPS;
+    // h*EPS < 2^63: the sum wrapped iff A's top bit is set and r's is clear (then r < 2^63 and r + EPS is the answer);
+    // otherwise r >= P iff r + EPS wraps (r's top bit set, t's clear)
+    return sel(ms_sar31(ms_bitop3<0x74>(hi(A), hi(r), hi(t))), t, r);
+  }
+  // 128-bit value folded with 2^64 == 2^32 - 1 and 2^96 == -1 (mod p):  lo - hi_hi + hi_lo * EPS
+  static MS_HD T reduce128(u64 lo_, u64 hi_) {
+    const u32 h0 = lo(hi_), h1 = hi(hi_);
+    const u64 A = lo_ - h1;                                        // wrapped iff lo < h1 < 2^32: lo's top bit clear, A's set
+    const u32 b1 = ms_bitop3<0x0C>(hi(lo_), hi(A), 0u);
+    const u64 U = (u64)h0 * 0xFFFFFFFFu;
+    const u64 r = A + U, t = r + EPS;
+    const u32 c1 = ms_bitop3<0xD4>(hi(A), hi(U), hi(r));           // carry out of A + U
+    const u32 c2 = ms_bitop3<0x30>(hi(r), hi(t), 0u);              // r >= P (when nothing wrapped)
+    // true value = r + (c1 - b1) * 2^64: +EPS if only the carry (or, with neither, r >= P), -EPS == +P if only the borrow
+    const u32 mm = ms_bitop3<0x30>(b1, c1, 0u);
+    const u64 rm = r + ms_pin64(mk(mm >> 31, ms_sar31(mm)));
+    return sel(ms_sar31(ms_bitop3<0x0E>(b1, c1, c2)), t, rm);
   }
   // 128-bit product as four 32x32+64 multiply-adds (v_mad_u64_u32): a*b and umul64hi separately cost two more multiplies
   static MS_HD T mul(T a, T b) {
@@ -54,6 +73,19 @@ struct GL {
     const u64 p10 = (u64)a1 * b0 + (u32)p01;
     const u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
     return reduce128((p10 << 32) | (u32)p00, p11);
+  }
+  // z * 2^32 and z * 2^64 for canonical z = z0 + z1 * 2^32
+  static MS_HD T mul_x32(T z) {                                     // z0 * 2^32 + z1 * EPS  (< 2^65)
+    const u64 L = (u64)lo(z) << 32, U = (u64)hi(z) * 0xFFFFFFFFu;
+    const u64 r = L + U, t = r + EPS;
+    const u32 c1 = ms_bitop3<0xD4>(hi(L), hi(U), hi(r));
+    return sel(ms_sar31(ms_bitop3<0xF4>(c1, hi(r), hi(t))), t, r);
+  }
+  static MS_HD T mul_x64(T z) {                                     // z0 * EPS - z1  (z0 >= 1 keeps it >= 0; both < P)
+    const u64 U = (u64)lo(z) * 0xFFFFFFFFu;
+    const u64 r = U - hi(z);
+    const u32 bo = ms_bitop3<0x0C>(hi(U), hi(r), 0u);              // wrapped iff U < z1 < 2^32
+    return r + ms_pin64(mk(bo >> 31, ms_sar31(bo)));
   }
   static MS_HD T from_u64(u64 v) { return v; }
   static MS_HD u64 to_u64(T v) { return v; }

@@ -171,7 +171,8 @@ template <class F> struct Ctx : CtxBase {
     for (auto& kv : sub_ms) {
       const int sub = kv.first; char name[160], buf[320];
       const char* fld = F::ID == 0 ? "GL" : "BB";
-      if (sub & 32) snprintf(name, sizeof name, "msntt::PassKernel<%s, %s, %d>", fld, (sub & 64) ? "true" : "false", (sub & 16) ? 512 : 256);
+      if (sub & 128) snprintf(name, sizeof name, "msntt::PassKernel2<%s, %s, %d, %d, 256>", fld, (sub & 64) ? "true" : "false", sub & 15, (sub >> 8) & 7);
+      else if (sub & 32) snprintf(name, sizeof name, "msntt::PassKernel<%s, %s, %d>", fld, (sub & 64) ? "true" : "false", (sub & 16) ? 512 : 256);
       else snprintf(name, sizeof name, "msntt::PassKernelK<%s, %s, %d, %d>", fld, (sub & 64) ? "true" : "false", sub & 15, (sub & 16) ? 512 : 256);
       snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"alg_bytes\": %.0f}", first ? "" : ", ", name, sub_cnt[sub], kv.second, sub_by[sub]);
       j += buf; first = false;
@@ -184,12 +185,15 @@ template <class F> struct Ctx : CtxBase {
   // ------------------------------------------------------------------ NTT plans
   struct Plan {
     int log_n = 0, log_r0 = 0, log_rho = 0, npass = 0, K[4] = {0, 0, 0, 0}, lo_bits = 0;
+    int LC[4] = {msntt::TILE_LOG_C, msntt::TILE_LOG_C, msntt::TILE_LOG_C, msntt::TILE_LOG_C};   // log2 tile columns of every pass
+    bool v2[4] = {false, false, false, false};                                                   // pass runs on msntt::PassKernel2
     DevBuf tw_lo, tw_hi, w_r[4], vtw, w0;
     T n_inv = 0;
   };
   std::map<int, Plan*> plans;  // key = (log_n*4 + log_pad)*2 + inverse
   DevBuf ntt_scratch;
   int ntt_kmax = 9;            // largest tile (log2 rows) of a multi-pass plan; MS_NTT_KMAX overrides (tuning)
+  int ntt_v2 = 1, ntt_v2_min = 14, ntt_v2_maxpass = 2;   // MS_NTT_V2=0: round-1 kernels only (A/B); transforms of at least 2^MS_NTT_V2_MIN points use the two-sub-round tiles
   int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1, ntt_fast = 1, ntt_fast_min = 22, ntt_fast_max = 24;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
 
   // log_pad: the input is zero beyond n >> log_pad
@@ -200,7 +204,19 @@ template <class F> struct Ctx : CtxBase {
     if (log_n > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "domain larger than the field's two-adicity");
     Plan* pl = new Plan();
     pl->log_n = log_n;
-    if (log_n <= msntt::MAX_LOG_R) { pl->npass = 1; pl->K[0] = log_n; }
+    const int v2_lc = (F::ID == 0) ? 3 : 4;   // 64-byte tile rows: 8 Goldilocks / 16 BabyBear columns
+    bool use_v2 = false;
+    if (ntt_v2 && log_n >= ntt_v2_min && log_n > msntt::MAX_LOG_R && (log_pad == 0 || log_pad == 3)) {
+      // passes of up to 2^10 rows; a blowup-8 evaluation starts behind the virtual radix-8 zero-padding pass (8 tile columns = its 8 cosets)
+      const int m = log_n - log_pad, P = (m + 9) / 10;
+      if (P <= ntt_v2_maxpass && m / P >= 7) {   // measured (r02): two passes of 2^10-row tiles beat three of 2^8; with three or more passes the round-1 tiles win
+        use_v2 = true;
+        pl->log_rho = 0; pl->log_r0 = log_pad; pl->npass = P;
+        for (int i = 0; i < P; i++) { pl->K[i] = m / P + (i < m % P ? 1 : 0); pl->LC[i] = (i == 0 && log_pad) ? 3 : v2_lc; pl->v2[i] = true; }
+      }
+    }
+    if (use_v2) {}
+    else if (log_n <= msntt::MAX_LOG_R) { pl->npass = 1; pl->K[0] = log_n; }
     else {
       // virtual first pass: radix 2^log_pad of pure zero padding times a real radix 2^log_rho (<= 4) over the
       // non-zero blocks; pick the smallest log_rho that minimises the number of real passes
@@ -286,8 +302,29 @@ template <class F> struct Ctx : CtxBase {
     next_sub = K | (TH == 512 ? 16 : 0) | (INV ? 64 : 0);
     return run<KK>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, TH, KK::lds_bytes(), pp);
   }
+  template <bool INV, int K, int LC>
+  int launch_v2(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
+    typedef msntt::PassKernel2<F, INV, K, LC, 256> KK;
+    if (!KK::applicable(pp)) return 998;   // NTT plan / PassKernel2 mismatch (a bug, not a runtime condition)
+    next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0);
+    return run<KK>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, 256, KK::lds_bytes(), pp);
+  }
+  template <bool INV, int LC>
+  int launch_v2k(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
+    switch (pp.log_r) {
+      case 7: return launch_v2<INV, 7, LC>(pp, tiles, batch);
+      case 8: return launch_v2<INV, 8, LC>(pp, tiles, batch);
+      case 9: return launch_v2<INV, 9, LC>(pp, tiles, batch);
+      case 10: return launch_v2<INV, 10, LC>(pp, tiles, batch);
+      default: return 999;
+    }
+  }
   template <bool INV>
-  int launch_pass(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
+  int launch_pass(const msntt::PassParams<F>& pp, size_t tiles, size_t batch, bool v2 = false) {
+    if (v2) {
+      if constexpr (F::ID == 0) return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : 997;
+      else return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : launch_v2k<INV, 4>(pp, tiles, batch);
+    }
     // compile-time specialised tiles for the large transforms (no virtual pass, 16 columns)
     if (ntt_fast && pp.log_C == msntt::TILE_LOG_C && pp.log_r0 == 0 && (pp.log_Rp == 0 || pp.log_Rp >= msntt::TILE_LOG_C)) {
       switch (pp.log_r) {
@@ -353,11 +390,11 @@ template <class F> struct Ctx : CtxBase {
       pp.log_n = log_n; pp.log_r = pl->K[k]; pp.log_Rp = log_Rp; pp.lo_bits = pl->lo_bits;
       pp.log_r0 = (k == 0) ? log_r0 : 0; pp.log_rho = (k == 0) ? pl->log_rho : 0;
       const int cols_log = log_n - pl->K[k];
-      pp.log_C = cols_log < msntt::TILE_LOG_C ? cols_log : msntt::TILE_LOG_C;
+      pp.log_C = cols_log < pl->LC[k] ? cols_log : pl->LC[k];
       pp.last = (k == P - 1);
       const size_t tiles = ((size_t)1 << cols_log) >> pp.log_C;
       next_bytes = (double)(n_in + n) * batch * sizeof(T) / P;  // (n_in + n)*s per transform, shared by its P real passes
-      if (inverse) CK(launch_pass<true>(pp, tiles, batch)); else CK(launch_pass<false>(pp, tiles, batch));
+      if (inverse) CK(launch_pass<true>(pp, tiles, batch, pl->v2[k])); else CK(launch_pass<false>(pp, tiles, batch, pl->v2[k]));
       in = out; in_bs = out_bs;
       log_Rp += pl->K[k];
     }
@@ -519,6 +556,9 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_MAXRHO")) { int v = atoi(e); if (v >= 0 && v <= msntt::MAX_LOG_RHO) ntt_maxrho = v; }
     if (const char* e = getenv("MS_NTT_TH512")) ntt_th512 = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
+    if (const char* e = getenv("MS_NTT_V2")) ntt_v2 = atoi(e);
+    if (const char* e = getenv("MS_NTT_V2_MAXPASS")) { int v = atoi(e); if (v >= 1 && v <= 4) ntt_v2_maxpass = v; }
+    if (const char* e = getenv("MS_NTT_V2_MIN")) { int v = atoi(e); if (v >= 12 && v <= 32) ntt_v2_min = v; }
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
     if (const char* e = getenv("MS_LEAF_LAZY_MIN")) leaf_lazy_min = atoi(e);

@@ -75,15 +75,9 @@ template <class F> struct PassParams {
 template <int S> MS_HD u64 gl_mul_pow2(u64 x) {
   static_assert(S >= 0 && S < 96, "shift out of range");
   if constexpr (S == 0) return x;
-  else if constexpr (S < 64) return GL::reduce128(x << S, x >> (64 - S));
-  else {  // x*2^S = x*2^(S-32)*2^32 = x*2^(S-32)*(2^64 - ... ) : use 2^64 == 2^32 - 1:  x*2^S == x*2^(S-32) - x*2^(S-64)
-    constexpr int A = S - 32, B = S - 64;  // 32 <= A < 64, 0 <= B < 32
-    const u64 alo = x << A, ahi = x >> (64 - A);
-    const u64 blo = x << B, bhi = (B == 0) ? 0 : (x >> ((64 - B) & 63));
-    const u64 lo = alo - blo;
-    const u64 hi = ahi - bhi - (alo < blo ? 1 : 0);
-    return GL::reduce128(lo, hi);
-  }
+  else if constexpr (S < 32) return GL::fold_small(ms_pin64(x << S), GL::hi(x) >> (32 - S));  // the S bits shifted out times 2^64 == EPS (pinned: one v_lshlrev_b64, its high word reused)
+  else if constexpr (S < 64) return GL::mul_x32(gl_mul_pow2<S - 32>(x));            // two steps: both stay canonical and branch-free
+  else return GL::mul_x64(gl_mul_pow2<S - 64>(x));
 }
 // (a - b) * w_(2^LOG2H2)^J for the reference's roots: w_64 = 2^39 (forward), 2^153 (inverse)
 template <class F, bool INV, int LOG2H2, int J> struct TwMul;
@@ -394,6 +388,199 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
         if (!p.last) { const size_t e = (size_t)inew * f; if (e) v = F::mul_tw(v, tw_global(p, e)); }
         if (do_scale) v = F::mul_tw(v, p.scale);
         dst[(f << K) + inew] = v;
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// PassKernel2: the large-transform pass of round 2.  A tile of 2^K rows x 2^LC columns (GL: 2^10 x 8 = 64 KiB, two workgroups per
+// CU) is transformed by TWO register sub-rounds of radix 2^B1 and 2^B2 (B1 = ceil(K/2) <= 5, B2 = K - B1): one general twiddle
+// multiplication inside the tile instead of two, ten butterfly stages per HBM pass instead of eight, so that a 2^20-point transform
+// (and, behind the virtual radix-8 zero-padding pass, the 2^23-point LDE of 2^20 coefficients) is TWO passes instead of three.
+// Measured background (tools/ntt_lab.hip, profiles/r02_ntt_lab.log): these kernels are bound by the NUMBER of VALU instructions
+// (~3.3-3.6 issue cycles each, whatever the opcode), an exec-masked formulation of the field arithmetic needs >= 4 waves per SIMD to
+// pay, and a 64 KiB tile leaves 2: hence compiler-scheduled sign-bit arithmetic (field.hpp) with 32 independent butterflies per thread.
+//
+// Global access is 16 bytes per lane (global_load/store_dwordx4: VEC = 2 Goldilocks / 4 BabyBear elements), a tile row is one
+// 64-byte run.  LDS: element (row, c) at row*C + c + (row >> B2)*PADE; PADE makes the three access patterns conflict-free
+// (sub-round 1: lanes over (lo, c), c fastest; sub-round 2: lanes over hi; row-wise load/store sweeps).
+// The w_r table (sub-round 1) and the per-row store twiddles (store phase) share one LDS region.
+// Cases (same index algebra as PassKernel above):
+//   log_r0 == 0, log_Rp == 0   first pass of a plain transform: transposed store, twiddle w_n^(i_new * f)
+//   log_r0 == 0, log_Rp >= LC  later pass: 64-byte output runs, one twiddle per tile row (none in the last pass)
+//   log_r0 == LC (GL: 3)       first pass behind the virtual zero-padding pass: the C columns of a tile are the r0 cosets of ONE
+//                              coefficient index, the tile's output is one contiguous block of r0 * r elements
+template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
+  typedef typename F::T T;
+  typedef PassParams<F> Params;
+  static constexpr int THREADS = TH;
+  static constexpr int R = 1 << K, C = 1 << LC;
+  static constexpr int B1 = (K + 1) / 2, B2 = K - B1, Q1 = 1 << B2;   // sub-round 1: top B1 row bits (distance Q1), sub-round 2: low B2 bits
+  static constexpr int PADE = (B1 >= 5) ? 1 : (32 >> B1);
+  static constexpr int VEC = 16 / (int)sizeof(T), LPR = C / VEC, RPS = TH / LPR, SWEEPS = R / RPS;  // lanes per row, rows per sweep
+  static constexpr int ITEMS1 = (R >> B1) * C, ITEMS2 = (R >> B2) * C;
+  static_assert(K >= 7 && K <= 10 && B1 <= 5 && C % VEC == 0 && TH % LPR == 0 && R % RPS == 0, "unsupported tile");
+  static_assert(ITEMS1 % TH == 0 || ITEMS1 < TH, "items");
+  struct alignas(16) V16 { T v[VEC]; };
+
+  static MS_HD int nphases(const Params&) { return 4; }
+  static MS_HD size_t tile_elems() { return (size_t)R * C + (size_t)(R >> B2) * PADE; }
+  static constexpr bool SHARE_W = (F::ID == 0);   // Goldilocks: the store twiddles reuse the w_r region (BabyBear's sub-round 2 still reads w_r)
+  static MS_HD size_t lds_bytes() { return (tile_elems() + (SHARE_W ? R : 2 * R)) * sizeof(T); }
+  static MS_HD int tix(int row, int c) { return row * C + c + (row >> B2) * PADE; }
+  static MS_HD bool applicable(const Params& p) {
+    return p.log_r == K && p.log_C == LC && p.log_rho == 0 && ((p.log_r0 == 0 && (p.log_Rp == 0 || p.log_Rp >= LC)) || (p.log_r0 == LC && p.log_Rp == LC));
+  }
+  static MS_DEV T tw_global(const Params& p, size_t e) {
+    T tw = p.tw_lo[e & (((size_t)1 << p.lo_bits) - 1)];
+    const size_t eh = e >> p.lo_bits;
+    if (eh) tw = F::mul_tw(tw, p.tw_hi[eh]);
+    return tw;
+  }
+  // logical tile of workgroup bx.  Behind the virtual pass the 2^LC... tiles that share 64-byte source lines are neighbours: give each
+  // XCD (workgroups are dealt round-robin over the 8 XCDs) a contiguous range of tiles so that those lines are fetched into ONE L2.
+  static MS_DEV size_t tile_of(const Params& p, int bx) {
+    const size_t tiles = ((size_t)1 << (p.log_n - K)) >> LC;
+    if (p.log_r0 && tiles >= 64) return (size_t)(bx & 7) * (tiles >> 3) + (size_t)(bx >> 3);
+    return (size_t)bx;
+  }
+
+  template <int B, int J> static MS_DEV void sub1_items(int tid, T* tile, const T* w) {
+    constexpr int NJ = (ITEMS1 + TH - 1) / TH;
+    const int it = tid + J * TH;
+    if (ITEMS1 >= TH || it < ITEMS1) {
+      const int c = it & (C - 1), lo = it >> LC;             // lanes: c fastest
+      T* base = tile + lo * C + c;                            // row lo + t*Q1: + t*(Q1*C + PADE)
+      T x[1 << B];
+#pragma unroll
+      for (int t = 0; t < (1 << B); t++) x[t] = base[t * (Q1 * C + PADE)];
+      dif_regs<F, INV, B>(x, w, K);
+#pragma unroll
+      for (int e = 0; e < (1 << B); e++) {
+        T v = x[bitrev(e, B)];
+        if (e != 0) v = F::mul_tw(v, w[e * lo]);              // w_r^(e * lo); lo == 0 multiplies by w[0] = 1
+        base[e * (Q1 * C + PADE)] = v;
+      }
+    }
+    if constexpr (J + 1 < NJ) sub1_items<B, J + 1>(tid, tile, w);
+  }
+  template <int B, int J> static MS_DEV void sub2_items(int tid, T* tile, const T* w) {
+    constexpr int NJ = (ITEMS2 + TH - 1) / TH;
+    const int it = tid + J * TH;
+    if (ITEMS2 >= TH || it < ITEMS2) {
+      const int hi = it & ((1 << B1) - 1), c = it >> B1;      // lanes: hi fastest
+      T* base = tile + hi * (Q1 * C + PADE) + c;              // row hi*Q1 + t: + t*C
+      T x[1 << B];
+#pragma unroll
+      for (int t = 0; t < (1 << B); t++) x[t] = base[t * C];
+      dif_regs<F, INV, B>(x, w, K);
+#pragma unroll
+      for (int e = 0; e < (1 << B); e++) base[e * C] = x[bitrev(e, B)];
+    }
+    if constexpr (J + 1 < NJ) sub2_items<B, J + 1>(tid, tile, w);
+  }
+
+  static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int, unsigned char* lds) {
+    T* tile = reinterpret_cast<T*>(lds);
+    T* w = tile + tile_elems();                  // [R]: w_r (phases 0-1), then the store twiddle of every tile row (phases 2-3)
+    const size_t n = (size_t)1 << p.log_n, cs = n >> K;
+    const size_t f0 = tile_of(p, bx) << LC;
+    const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
+    if (ph == 0) {
+      const T* src = p.src + (size_t)by * p.src_bstride;
+      if (p.log_r0 == 0) {
+        if (p.n_in >= n) {
+          V16 buf[SWEEPS];
+          const T* s0 = src + f0 + c0 + (size_t)rb * cs;
+#pragma unroll
+          for (int i = 0; i < SWEEPS; i++) buf[i] = *reinterpret_cast<const V16*>(s0 + (size_t)(i * RPS) * cs);
+#pragma unroll
+          for (int i = 0; i < SWEEPS; i++) {
+            T* d = tile + tix(rb + i * RPS, c0);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) d[v] = buf[i].v[v];
+          }
+        } else {
+          for (int i = 0; i < SWEEPS; i++) {
+            const size_t a = f0 + c0 + (size_t)(rb + i * RPS) * cs;
+            T* d = tile + tix(rb + i * RPS, c0);
+            for (int v = 0; v < VEC; v++) d[v] = (a + v < p.n_in) ? src[a + v] : (T)0;
+          }
+        }
+      } else {
+        // virtual r0-point pass (r0 = C, only the first n/r0 inputs non-zero): A_1[k2*r0 + i1] = w_n^(i1*k) x[k], k = k2 + nprime*row.
+        // The k2 part of the twiddle rides on the store twiddle; here x[k] * w_(r0 r)^(i1 * row).  One lane per tile element.
+        const size_t k2 = f0 >> LC, nprime = n >> (LC + K);
+        for (int idx = tid; idx < R * C; idx += TH) {
+          const int row = idx >> LC, i1 = idx & (C - 1);
+          const size_t k = k2 + nprime * (size_t)row;
+          T v = (k < p.n_in) ? src[k] : (T)0;
+          if (i1) v = F::mul_tw(v, p.vtw[(size_t)i1 * row]);
+          tile[tix(row, i1)] = v;
+        }
+      }
+      for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
+      return;
+    }
+    if (ph == 1) { sub1_items<B1, 0>(tid, tile, w); return; }
+    T* twr = w + (SHARE_W ? 0 : R);                  // [R] store twiddle of every tile row
+    const bool row_tw = !p.last && p.log_Rp >= LC && (f0 >> p.log_Rp) != 0;
+    if (ph == 2) {
+      if (row_tw) {                                  // Goldilocks: w_r is dead after sub-round 1 (its in-register twiddles are shifts)
+        const size_t k_low = f0 >> p.log_Rp;
+        for (int row = tid; row < R; row += TH) {
+          const int inew = (row >> B2) | ((row & (Q1 - 1)) << B1);
+          twr[row] = tw_global(p, ((size_t)inew * k_low) << p.log_Rp);   // w_n^(k_low * Rp * i_new)
+        }
+      }
+      sub2_items<B2, 0>(tid, tile, w);
+      return;
+    }
+    // ---- store phase
+    T* dst = p.dst + (size_t)by * p.dst_bstride;
+    const bool do_scale = p.do_scale != 0;
+    if (p.log_Rp >= LC) {
+      // out = k_low*Rp*r + i_done + Rp*i_new: a tile row is one 16*LPR-byte run
+      const size_t k_low = f0 >> p.log_Rp, i_done0 = (f0 & (((size_t)1 << p.log_Rp) - 1)) + c0;
+      T* out = dst + ((k_low << p.log_Rp) << K) + i_done0;
+      T gc[VEC];                                     // behind the virtual pass: w_n^(k_low * i_done), i_done = the column
+      const bool col_tw = row_tw && p.log_r0 != 0;
+#pragma unroll
+      for (int v = 0; v < VEC; v++) gc[v] = col_tw ? tw_global(p, k_low * (size_t)(c0 + v)) : F::to_tw(F::from_u64(1));
+#pragma unroll 4
+      for (int i = 0; i < SWEEPS; i++) {
+        const int row = rb + i * RPS;
+        const int inew = (row >> B2) | ((row & (Q1 - 1)) << B1);
+        const T* sp = tile + tix(row, c0);
+        const T rt = row_tw ? twr[row] : F::to_tw(F::from_u64(1));
+        V16 o;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          T x = sp[v];
+          if (row_tw) x = F::mul_tw(x, rt);
+          if (col_tw && (c0 + v)) x = F::mul_tw(x, gc[v]);
+          if (do_scale) x = F::mul_tw(x, p.scale);
+          o.v[v] = x;
+        }
+        *reinterpret_cast<V16*>(out + ((size_t)inew << p.log_Rp)) = o;
+      }
+    } else {
+      // first pass of a plain transform: out = f*r + i_new, i_new fastest across lanes
+      for (int idx = tid * VEC; idx < R * C; idx += TH * VEC) {
+        const int c = idx >> K, inew0 = idx & (R - 1);
+        const size_t f = f0 + c;
+        V16 o;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          const int inew = inew0 + v;
+          const int row = ((inew & ((1 << B1) - 1)) << B2) | (inew >> B1);
+          T x = tile[tix(row, c)];
+          if (!p.last) { const size_t e = (size_t)inew * f; if (e) x = F::mul_tw(x, tw_global(p, e)); }
+          if (do_scale) x = F::mul_tw(x, p.scale);
+          o.v[v] = x;
+        }
+        *reinterpret_cast<V16*>(dst + (f << K) + inew0) = o;
       }
     }
   }

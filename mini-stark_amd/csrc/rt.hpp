@@ -137,3 +137,26 @@ MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) {
 #endif
 }
 #endif
+
+// ---- bit-level helpers shared by the three builds ---------------------------------------------
+// Arbitrary 3-input bit function, truth table TT indexed by (a << 2 | b << 1 | c).  gfx950: ONE v_bitop3_b32, which issues at
+// the full VALU rate (~2.7 cycles per wave-instruction) where compares, v_cndmask and carry ops cost ~4.5
+// (profiles/r01_valu_issue_rate.txt) and compares additionally route their result through an SGPR pair (2 wait states before use).
+template <int TT> MS_HD uint32_t ms_bitop3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+  return ((TT & 1) ? (~a & ~b & ~c) : 0u) | ((TT & 2) ? (~a & ~b & c) : 0u) | ((TT & 4) ? (~a & b & ~c) : 0u) | ((TT & 8) ? (~a & b & c) : 0u) |
+         ((TT & 16) ? (a & ~b & ~c) : 0u) | ((TT & 32) ? (a & ~b & c) : 0u) | ((TT & 64) ? (a & b & ~c) : 0u) | ((TT & 128) ? (a & b & c) : 0u);
+#endif
+}
+// all-ones if bit 31 is set, else zero (v_ashrrev_i32)
+MS_HD uint32_t ms_sar31(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }
+// keeps a 64-bit value materialised as ONE register pair (stops the compiler from splitting "x + (lo | hi << 32)" into two adds)
+MS_HD uint64_t ms_pin64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(v));
+#endif
+  return v;
+}
+

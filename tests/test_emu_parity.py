@@ -40,7 +40,7 @@ def test_ntt_three_pass(mk):
 
 
 @pytest.mark.parametrize("field", [0, 1])
-@pytest.mark.parametrize("log_n,blowup", [(3, 2), (4, 8), (9, 4), (12, 8)])
+@pytest.mark.parametrize("log_n,blowup", [(3, 2), (4, 8), (9, 4), (12, 8), (14, 8), (15, 8), (16, 4)])
 def test_coset_lde(mk, field, log_n, blowup):
     pc.case_coset_lde(mk, field, log_n, blowup)
 

@@ -1,0 +1,249 @@
+// ntt_lab.hip — arithmetic micro-benchmark behind the NTT pass design (MI355X): radix-2^B DIF butterfly networks on register-resident
+// Goldilocks values, no memory traffic, for several formulations of the modular add / sub / shift-multiply.  Reports ns per
+// butterfly-stage-element and VALU instructions are read off the ISA (hipcc -S).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include "../mini-stark_amd/csrc/ntt.hpp"
+
+// ---- variant 0: the r01 formulation (compare + select), kept here for A/B
+struct GL0 {
+  static constexpr u64 P = GL::P, EPS = GL::EPS;
+  static MS_HD u64 add(u64 a, u64 b) { const u64 s = a + b; const u64 t = s - P; return (s < a || s >= P) ? t : s; }
+  static MS_HD u64 sub(u64 a, u64 b) { u64 d = a - b; if (a < b) d -= EPS; return d; }
+  static MS_HD u64 reduce128(u64 lo, u64 hi) {
+    const u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
+    u64 t0 = lo - hi_hi; t0 -= (lo < hi_hi) ? EPS : 0;
+    const u64 t1 = (hi_lo << 32) - hi_lo;
+    const u64 r = t0 + t1; const u64 r2 = r + EPS;
+    return (r < t1 || r >= P) ? r2 : r;
+  }
+  template <int S> static MS_HD u64 mul_pow2(u64 x) {
+    if constexpr (S == 0) return x;
+    else if constexpr (S < 64) return reduce128(x << S, x >> (64 - S));
+    else { constexpr int A = S - 32, B = S - 64; const u64 alo = x << A, ahi = x >> (64 - A); const u64 blo = x << B, bhi = (B == 0) ? 0 : (x >> ((64 - B) & 63));
+      const u64 lo = alo - blo; const u64 hi = ahi - bhi - (alo < blo ? 1 : 0); return reduce128(lo, hi); }
+  }
+};
+// ---- variant 1: the r02 formulation (sign-bit decisions via v_bitop3)
+struct GL1 {
+  static MS_HD u64 add(u64 a, u64 b) { return GL::add(a, b); }
+  static MS_HD u64 sub(u64 a, u64 b) { return GL::sub(a, b); }
+  template <int S> static MS_HD u64 mul_pow2(u64 x) { return msntt::gl_mul_pow2<S>(x); }
+};
+// ---- variant 2: LAZY (NOT exact: single-fix add/sub on [0, 2^64), for cost exploration only)
+struct GL2 {
+  static MS_HD u64 add(u64 a, u64 b) { const u64 s = a + b; const u32 c = ms_bitop3<0xD4>(GL::hi(a), GL::hi(b), GL::hi(s)); return s + ms_pin64(GL::mk(ms_sar31(c), 0u)); }
+  static MS_HD u64 sub(u64 a, u64 b) { const u64 d = a - b; const u32 bo = ms_bitop3<0x8E>(GL::hi(a), GL::hi(b), GL::hi(d)); return d + ms_pin64(GL::mk(bo >> 31, ms_sar31(bo))); }
+  template <int S> static MS_HD u64 mul_pow2(u64 x) { return msntt::gl_mul_pow2<S>(x); }
+};
+
+// ---- variant 3: canonical, corrections under an EXEC mask instead of selects (inline asm; SALU does the mask plumbing)
+struct GL3 {
+  static __device__ __forceinline__ u64 add(u64 a, u64 b) {
+    u64 s, sv;
+    asm("v_lshl_add_u64 %0, %2, 0, %3\n\t"
+        "v_cmp_lt_u64 vcc, %0, %2\n\t"
+        "v_cmp_lt_u64 %1, %4, %0\n\t"
+        "s_or_b64 vcc, vcc, %1\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %5\n\t"
+        "s_mov_b64 exec, %1"
+        : "=&v"(s), "=&s"(sv) : "v"(a), "v"(b), "s"(GL::P - 1), "s"(GL::EPS) : "vcc", "scc");
+    return s;
+  }
+  static __device__ __forceinline__ u64 sub(u64 a, u64 b) {
+    u64 d = a - b, sv;
+    asm("v_cmp_lt_u64 vcc, %2, %3\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(d), "=&s"(sv) : "v"(a), "v"(b), "s"(GL::P) : "vcc", "scc");
+    return d;
+  }
+  // A + h * EPS, canonical (A any u64, h < 2^32 with A + h*EPS < 2^65 - ...: one wrap at most)
+  static __device__ __forceinline__ u64 fold(u64 A, u32 h) {
+    u64 sv;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %0\n\t"
+        "v_cmp_lt_u64 %1, %3, %0\n\t"
+        "s_or_b64 vcc, vcc, %1\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(A), "=&s"(sv) : "v"(h), "s"(GL::P - 1), "s"(GL::EPS) : "vcc", "scc");
+    return A;
+  }
+  static __device__ __forceinline__ u64 mul_x32(u64 z) { return fold(z << 32, GL::hi(z)); }
+  static __device__ __forceinline__ u64 mul_x64(u64 z) {       // z0 * EPS - z1
+    u64 U = (u64)GL::lo(z) * 0xFFFFFFFFu;
+    u64 r = U - GL::hi(z), sv;
+    asm("v_cmp_lt_u64 vcc, %2, %3\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(r), "=&s"(sv) : "v"(U), "v"((u64)GL::hi(z)), "s"(GL::P) : "vcc", "scc");
+    return r;
+  }
+  template <int S> static __device__ __forceinline__ u64 mul_pow2(u64 x) {
+    if constexpr (S == 0) return x;
+    else if constexpr (S < 32) return fold(x << S, GL::hi(x) >> (32 - S));
+    else if constexpr (S < 64) return mul_x32(mul_pow2<S - 32>(x));
+    else return mul_x64(mul_pow2<S - 64>(x));
+  }
+  static __device__ __forceinline__ u64 mul(u64 a, u64 b) {
+    u64 T0, M, T1, c;
+    asm("v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
+        "v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %2, vcc, %5, %7, 0\n\t"
+        "v_mad_u64_u32 %1, %3, %5, %6, %1"
+        : "=&v"(T0), "=&v"(M), "=&v"(T1), "=&s"(c) : "v"(GL::lo(a)), "v"(GL::hi(a)), "v"(GL::lo(b)), "v"(GL::hi(b)) : "vcc");
+    // 128-bit (lo, hi) = T0 + M * 2^32 + T1 * 2^64 + c * 2^96;  r = lo - hi_hi (+ hi_lo * EPS below)
+    u32 L1, H0, H1, R0, R1; u64 bm;
+    asm("v_addc_co_u32 %2, vcc, %9, 0, %11\n\t"          // H1 = hi(T1) + c   (no wrap: the product is < 2^128)
+        "v_add_co_u32 %0, vcc, %6, %7\n\t"               // L1 = hi(T0) + lo(M)
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %1, vcc, %10, %8, vcc\n\t"        // H0 = lo(T1) + hi(M) + carry
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %2, vcc, %2, 0, vcc\n\t"          // H1 += carry
+        "v_sub_co_u32 %3, vcc, %12, %2\n\t"              // r = lo - H1
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %4, vcc, 0, %0, vcc\n\t"
+        "s_mov_b64 %5, vcc"
+        : "=&v"(L1), "=&v"(H0), "=&v"(H1), "=&v"(R0), "=&v"(R1), "=&s"(bm)
+        : "v"(GL::hi(T0)), "v"(GL::lo(M)), "v"(GL::hi(M)), "v"(GL::hi(T1)), "v"(GL::lo(T1)), "s"(c), "v"(GL::lo(T0)) : "vcc");
+    u64 R = GL::mk(R0, R1), sv;
+    asm("s_and_saveexec_b64 %1, %3\n\t"                  // borrow: r += P  (== - EPS)
+        "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %2, -1, %0\n\t"          // + hi_lo * EPS, carry in vcc
+        "v_cmp_lt_u64 %1, %5, %0\n\t"
+        "s_or_b64 vcc, vcc, %1\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %6\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(R), "=&s"(sv) : "v"(H0), "s"(bm), "s"(GL::P), "s"(GL::P - 1), "s"(GL::EPS) : "vcc", "scc");
+    return R;
+  }
+};
+
+template <class A, int LOG2H2, int J> __device__ __forceinline__ u64 tw(u64 a, u64 b) {
+  constexpr int EXP = (39 * (64 >> LOG2H2) * J) % 192;
+  if constexpr (EXP >= 96) return A::template mul_pow2<EXP - 96>(A::sub(b, a));
+  else return A::template mul_pow2<EXP>(A::sub(a, b));
+}
+template <class A, int B, int S, int BLK, int J> struct Stage {
+  static __device__ __forceinline__ void run(u64 (&x)[1 << B]) {
+    constexpr int h = 1 << S;
+    u64 a = x[BLK + J], b = x[BLK + J + h];
+    x[BLK + J] = A::add(a, b);
+    if constexpr (J == 0) x[BLK + J + h] = A::sub(a, b); else x[BLK + J + h] = tw<A, S + 1, J>(a, b);
+    if constexpr (J + 1 < h) Stage<A, B, S, BLK, J + 1>::run(x);
+    else if constexpr (BLK + 2 * h < (1 << B)) Stage<A, B, S, BLK + 2 * h, 0>::run(x);
+    else if constexpr (S > 0) Stage<A, B, S - 1, 0, 0>::run(x);
+  }
+};
+template <class A, int B, int MODE> __global__ void __launch_bounds__(256) lab(u64* out, const u64* in, int iters) {
+  u64 x[1 << B];
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  for (int i = 0; i < (1 << B); i++) x[i] = in[(tid * 7 + i * 13) & 4095];
+  for (int it = 0; it < iters; it++) {
+    if (MODE == 0) Stage<A, B, B - 1, 0, 0>::run(x);                                      // full radix-2^B DIF (adds, subs, shift twiddles)
+    if (MODE == 1) { for (int i = 0; i < (1 << B); i += 2) { u64 a = x[i], b = x[i + 1]; x[i] = A::add(a, b); x[i + 1] = A::sub(a, b); } }  // add/sub only
+    if (MODE == 2) { _Pragma("unroll") for (int i = 0; i < (1 << B); i++) x[i] = GL::mul(x[i], x[(i + 1) & ((1 << B) - 1)]); }               // general multiplies
+    if constexpr (MODE == 3) { _Pragma("unroll") for (int i = 0; i < (1 << B); i++) x[i] = A::mul(x[i], x[(i + 1) & ((1 << B) - 1)]); }
+  }
+  u64 s = 0;
+  for (int i = 0; i < (1 << B); i++) s ^= x[i];
+  out[tid] = s;
+}
+static int g_lds = 0;   // dynamic LDS per workgroup: limits the workgroups resident per CU (occupancy experiments)
+template <class A, int B, int MODE> void run(const char* name, u64* d_out, u64* d_in, int blocks, double ops_per_iter_per_thread) {
+  const int iters = 200;
+  if (g_lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(&lab<A, B, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, g_lds);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((lab<A, B, MODE>), dim3(blocks), dim3(256), g_lds, 0, d_out, d_in, 2);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((lab<A, B, MODE>), dim3(blocks), dim3(256), g_lds, 0, d_out, d_in, iters);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  const double total = (double)blocks * 256 * iters * ops_per_iter_per_thread;
+  // lane-cycles per op at 2.4 GHz with all 256 CUs x 4 SIMDs x 32 lanes busy... report lane-ns instead: chip lanes = 256*4*64 wave-lanes per "cycle slot"
+  const double lane_cycles = ms * 1e-3 * 2.4e9 * 256 * 4 * 64 / total;
+  printf("%-44s blocks %5d  %8.3f ms  %8.1f wave64-lane-cycles per op (2.4 GHz nominal)\n", name, blocks, ms, lane_cycles);
+}
+template <class A> __global__ void check_k(u64* out, const u64* in, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 a = in[i], b = in[(i * 7 + 3) % n];
+  u64* o = out + (size_t)i * 12;
+  o[0] = A::add(a, b); o[1] = A::sub(a, b); o[2] = A::mul(a, b);
+  o[3] = A::template mul_pow2<3>(a); o[4] = A::template mul_pow2<31>(a); o[5] = A::template mul_pow2<32>(a); o[6] = A::template mul_pow2<45>(a);
+  o[7] = A::template mul_pow2<63>(a); o[8] = A::template mul_pow2<64>(a); o[9] = A::template mul_pow2<78>(a); o[10] = A::template mul_pow2<95>(a); o[11] = A::template mul_pow2<12>(b);
+}
+struct GLr { static MS_HD u64 add(u64 a, u64 b) { return GL::add(a, b); } static MS_HD u64 sub(u64 a, u64 b) { return GL::sub(a, b); } static MS_HD u64 mul(u64 a, u64 b) { return GL::mul(a, b); }
+  template <int S> static MS_HD u64 mul_pow2(u64 x) { return msntt::gl_mul_pow2<S>(x); } };
+static u64 href_mulmod(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % GL::P); }
+template <class A> int check(const char* name) {
+  const int n = 1 << 16;
+  std::vector<u64> h(n);
+  u64 s = 0x243F6A8885A308D3ull;
+  for (int i = 0; i < n; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = s % GL::P; }
+  const u64 edge[] = {0, 1, 2, GL::P - 1, GL::P - 2, 0xFFFFFFFFull, 0x100000000ull, 0xFFFFFFFF00000000ull, 0xFFFFFFFEFFFFFFFFull, 0x8000000000000000ull, 0x7FFFFFFFFFFFFFFFull, 0xFFFFFFFEull, 0x00000001FFFFFFFFull};
+  for (int i = 0; i < n; i++) if ((i % 5) == 0) h[i] = edge[(i / 5) % 13];
+  for (int i = 0; i < 13 * 13; i++) { h[1000 + 2 * i] = edge[i / 13]; }
+  u64 *d_in, *d_out; hipMalloc(&d_in, n * 8); hipMalloc(&d_out, (size_t)n * 12 * 8);
+  hipMemcpy(d_in, h.data(), n * 8, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL((check_k<A>), dim3(n / 256), dim3(256), 0, 0, d_out, d_in, n);
+  std::vector<u64> o((size_t)n * 12);
+  hipError_t e = hipMemcpy(o.data(), d_out, o.size() * 8, hipMemcpyDeviceToHost);
+  int bad = 0;
+  const int sh[9] = {3, 31, 32, 45, 63, 64, 78, 95, 12};
+  for (int i = 0; i < n && bad < 10; i++) {
+    const u64 a = h[i], b = h[(i * 7 + 3) % n];
+    u64 want[12]; want[0] = (u64)(((unsigned __int128)a + b) % GL::P); want[1] = (u64)(((unsigned __int128)a + GL::P - b) % GL::P); want[2] = href_mulmod(a, b);
+    for (int k = 0; k < 9; k++) { u64 pw = 1; for (int t = 0; t < sh[k]; t++) pw = href_mulmod(pw, 2); want[3 + k] = href_mulmod(k == 8 ? b : a, pw); }
+    for (int k = 0; k < 12; k++) if (o[(size_t)i * 12 + k] != want[k]) { printf("  %s MISMATCH op %d a=%llx b=%llx got %llx want %llx\n", name, k, (unsigned long long)a, (unsigned long long)b, (unsigned long long)o[(size_t)i * 12 + k], (unsigned long long)want[k]); bad++; }
+  }
+  printf("check %-28s %s (hip status %d)\n", name, bad ? "FAILED" : "ok: add sub mul and 9 shift-multiplies exact on 65536 pairs incl. edge values", (int)e);
+  hipFree(d_in); hipFree(d_out);
+  return bad;
+}
+int main() {
+  check<GLr>("r02 bit-trick (field.hpp)");
+  check<GL3>("masked asm");
+
+  u64 *d_in, *d_out;
+  std::vector<u64> h(4096);
+  u64 s = 88172645463325252ull;
+  for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = s % GL::P; }
+  hipMalloc(&d_in, 4096 * 8); hipMalloc(&d_out, 8192 * 256 * 8);
+  hipMemcpy(d_in, h.data(), 4096 * 8, hipMemcpyHostToDevice);
+  for (int lds : {0, 40 << 10, 72 << 10, 140 << 10}) {   // 8 (register-limited), 4, 2, 1 workgroups of 4 waves per CU
+    const int blocks = 4096; g_lds = lds;
+    printf("==== dynamic LDS %d KiB per workgroup\n", lds >> 10);
+    run<GL0, 5, 0>("r01 radix-32 DIF", d_out, d_in, blocks, 32 * 5);
+    run<GL1, 5, 0>("r02 radix-32 DIF", d_out, d_in, blocks, 32 * 5);
+    run<GL3, 5, 0>("masked-asm radix-32 DIF", d_out, d_in, blocks, 32 * 5);
+    run<GL3, 4, 0>("masked-asm radix-16 DIF", d_out, d_in, blocks, 16 * 4);
+    run<GL3, 4, 3>("masked-asm general multiply (16 values)", d_out, d_in, blocks, 16);
+  }
+  g_lds = 0;
+  for (int blocks : {4096}) {   // 1, 2, 4, 8 workgroups (4, 8, 16, 32 waves) per CU if registers allow
+    printf("---- %d workgroups of 256 threads\n", blocks);
+    // op = one element through one butterfly stage
+    run<GL0, 4, 1>("r01 add/sub only (16 values)", d_out, d_in, blocks, 16);
+    run<GL1, 4, 1>("r02 add/sub only (16 values)", d_out, d_in, blocks, 16);
+    run<GL2, 4, 1>("lazy add/sub only (16 values, inexact)", d_out, d_in, blocks, 16);
+    run<GL0, 4, 0>("r01 radix-16 DIF", d_out, d_in, blocks, 16 * 4);
+    run<GL1, 4, 0>("r02 radix-16 DIF", d_out, d_in, blocks, 16 * 4);
+    run<GL2, 4, 0>("lazy radix-16 DIF (inexact)", d_out, d_in, blocks, 16 * 4);
+    run<GL3, 4, 0>("masked-asm radix-16 DIF", d_out, d_in, blocks, 16 * 4);
+    run<GL3, 5, 0>("masked-asm radix-32 DIF", d_out, d_in, blocks, 32 * 5);
+    run<GL0, 5, 0>("r01 radix-32 DIF", d_out, d_in, blocks, 32 * 5);
+    run<GL1, 5, 0>("r02 radix-32 DIF", d_out, d_in, blocks, 32 * 5);
+    run<GL1, 4, 2>("general multiply (16 values)", d_out, d_in, blocks, 16);
+    run<GL3, 4, 3>("masked-asm general multiply (16 values)", d_out, d_in, blocks, 16);
+  }
+  return 0;
+}
