@@ -83,6 +83,20 @@ int ms_synchronize(ms_ctx* ctx);
 typedef enum { MS_XCHG_ALL_TO_ALL = 0, MS_XCHG_ALL_GATHER = 1, MS_XCHG_ALL_REDUCE_MIN_U64 = 2, MS_XCHG_ALL_REDUCE_SUM_U8 = 3 } ms_xchg_op;
 typedef int (*ms_exchange_fn)(void* user, int op, size_t bytes);
 int ms_set_shard(ms_ctx* ctx, int rank, int world, void* d_send, void* d_recv, size_t cap_bytes, ms_exchange_fn fn, void* user);
+/* The production form: the library runs the four collectives itself with RCCL (ncclSend/ncclRecv in one group, ncclAllGather,
+ * ncclAllReduce) ON THE CONTEXT'S STREAM - stream-ordered with the kernels on both sides, no stream synchronisation, no host
+ * callback - and owns the two exchange buffers (`cap_bytes` each: 32 * leaf groups of the largest commitment / world + 4 MiB).
+ * Rank 0 obtains `unique_id` (ncclGetUniqueId) with ms_rccl_unique_id and hands the 128 bytes to every rank through whatever
+ * channel the caller has (bench.py: a torch.distributed broadcast); every rank then calls ms_set_shard_rccl (collective:
+ * ncclCommInitRank).  librccl.so is bound at run time (dlopen; env MS_RCCL_LIB overrides the name): MS_ERR_HIP if it is absent.
+ * ms_set_shard above stays as the seam for callers without RCCL (the gloo tests on the kernel-emulation build). */
+int ms_rccl_unique_id(uint8_t out[128]);
+int ms_set_shard_rccl(ms_ctx* ctx, int rank, int world, const uint8_t unique_id[128], size_t cap_bytes);
+/* the four collectives on a ONE-rank RCCL communicator with known payloads: checks the run-time binding (symbols, enums, the
+ * by-value ncclUniqueId) and the stream ordering on a single GPU */
+int ms_rccl_selftest(ms_ctx* ctx);
+/* collective calls [0..3] and bytes sent [4..7] by this rank so far, per ms_xchg_op */
+int ms_shard_stats(ms_ctx* ctx, uint64_t out[8]);
 
 /* ---- src/util.rs:4-44, src/starks.rs:268-332 (host-only config math) ----- */
 int ms_is_power_of_two(uint64_t n);

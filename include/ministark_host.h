@@ -1,0 +1,59 @@
+/* ministark_host.h — C entry points of libministark_host.so: the host-side mirror of the reference's prover API ABOVE
+ * the C ABI of ministark.h (mini-stark_amd/host/stark_host.cpp: StarkConfig::new src/starks.rs:268-310, Stark::prove
+ * src/starks.rs:59-169, Stark::verify src/starks.rs:171-235 with Fri::verify src/fri.rs:191-290 and MerkleRoot::check_proof
+ * src/merkle.rs:312-338) and the whole-proof wire format.  The reference is Rust and derives no serialisation for StarkProof
+ * (src/starks.rs:21-28), FriProof (src/fri.rs:17-22) or MerklePath (src/merkle.rs:293-298): both layouts below are build-defined.
+ *
+ * MSSP v1 (little-endian):
+ *   u32 magic 'MSSP' | u32 version 1 | u32 E | u32 c | u32 q | u32 rounds | u64 len(arthur) | u64 len(fri blob)
+ *   trace_commit[32] | constrain_trace_commit[32]
+ *   constrain_queries q*c*E u64 | validity_queries q*E u64                     (StarkProof.constrain_queries / validity_query)
+ *   fri_roots rounds*32   (round 0 first; not in the reference's StarkProof: round 0's root never reaches its transcript)
+ *   arthur bytes          (the prover's transcript, StarkProof.arthur; build-defined SHA-256 chain, NOT nimue's bytes)
+ *   FriProof in the MSFP layout of ministark.h
+ * The Python mirror writes the same bytes (mini_stark_amd.stark.StarkProof.to_bytes). */
+#ifndef MINISTARK_HOST_H
+#define MINISTARK_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#include "ministark.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct msh_stark msh_stark;
+typedef struct {
+  uint32_t e, c, q, rounds;
+  uint64_t arthur_len, fri_blob_len;
+  const uint8_t *trace_commit, *constrain_trace_commit, *fri_roots, *arthur, *fri_blob;
+  const uint64_t *constrain_queries, *validity_queries;
+} msh_proof_view;
+
+/* StarkConfig::new + Stark::new (starks.rs:268-310, 40-57); NULL and *err = MS_ERR_SHAPE for < 20 security bits (starks.rs:317-320) */
+msh_stark* msh_stark_new(ms_ctx* ctx, int field, uint64_t security_bits, uint64_t blowup, uint64_t steps, uint64_t trace_columns, int* err);
+void msh_stark_free(msh_stark* h);
+int msh_stark_config(const msh_stark* h, uint64_t* rounds, uint64_t* constrain_queries, uint64_t* fri_queries);
+/* Stark::prove (starks.rs:59-169): trace from host memory or already in HBM; transitions as lincombs of trace polynomials */
+int msh_stark_prove(msh_stark* h, const uint64_t* trace_host, const void* trace_dev, size_t N, size_t w, int ntrans, const int* tr_k,
+                    const uint64_t* tr_scalars, const int* tr_idx, int read_fri_proof);
+size_t msh_proof_arthur(const msh_stark* h, uint8_t* out, size_t cap);
+int msh_proof_commits(const msh_stark* h, uint8_t* trace_commit, uint8_t* lde_commit);
+size_t msh_proof_evals(const msh_stark* h, uint64_t* out, size_t cap_elems);
+size_t msh_proof_fri_roots(const msh_stark* h, uint8_t* out, size_t cap);
+size_t msh_proof_fri_blob(const msh_stark* h, uint8_t* out, size_t cap);
+size_t msh_proof_challenges(const msh_stark* h, uint64_t* out, size_t cap_elems);
+size_t msh_proof_num_polys(const msh_stark* h);
+/* Stark::verify (starks.rs:171-235) on the CPU.  A PARITY MIRROR of the reference's verifier, including what it does NOT bind
+ * (INTEGRATION.md "verifier"): 1 accepted, 0 rejected, < 0 malformed. */
+int msh_stark_verify(const msh_stark* h, const uint64_t* constrains, size_t c, size_t N, const uint8_t* arthur, size_t arthur_len, const uint8_t* trace_commit,
+                     const uint8_t* lde_commit, const uint64_t* evals, size_t nevals, const uint8_t* fri_roots, size_t nroots, const uint8_t* blob, size_t blob_len,
+                     int zero_display_empty, char* why, size_t why_cap);
+/* MSSP: serialise the last proof (returns the size needed; writes when cap suffices), parse (views into the buffer), verify from bytes */
+size_t msh_proof_serialize(const msh_stark* h, uint8_t* out, size_t cap);
+int msh_proof_parse(const uint8_t* data, size_t len, msh_proof_view* out);
+int msh_stark_verify_mssp(const msh_stark* h, const uint64_t* constrains, size_t c, size_t N, const uint8_t* data, size_t len, int zero_display_empty, char* why, size_t why_cap);
+/* synthetic Fibonacci-AIR trace of the benchmark workload (N x 3 row-major) */
+int msh_fibonacci_rows(uint64_t p, size_t length, size_t steps, uint64_t secret_b, uint64_t pad_seed, uint64_t* out);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -129,6 +129,24 @@ class Context:
         self.L.ms_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, EXCHANGE_FN, C.c_void_p]
         self.check(self.L.ms_set_shard(self.h, rank, world, send_ptr, recv_ptr, cap_bytes, self._xchg_cb, None))
 
+    def rccl_unique_id(self) -> bytes:
+        """ms_rccl_unique_id: the 128-byte ncclUniqueId rank 0 hands to every rank (any channel) before set_shard_rccl."""
+        buf = (C.c_uint8 * 128)()
+        rc = self.L.ms_rccl_unique_id(buf)
+        if rc != 0:
+            raise MsError(rc, "RCCL is not available (librccl.so could not be loaded)")
+        return bytes(buf)
+
+    def set_shard_rccl(self, rank, world, unique_id: bytes, cap_bytes: int):
+        """ms_set_shard_rccl: one proof over `world` ranks, the collectives run by the library itself with RCCL on its stream."""
+        self.L.ms_set_shard_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        self.check(self.L.ms_set_shard_rccl(self.h, rank, world, unique_id, cap_bytes))
+
+    def shard_stats(self):
+        out = (C.c_uint64 * 8)()
+        self.check(self.L.ms_shard_stats(self.h, out))
+        return [int(v) for v in out]
+
     # ---- Stark::prove stages ---------------------------------------------------
     def trace_commit(self, trace, lpn):
         t = np.ascontiguousarray(trace, dtype=np.uint64)

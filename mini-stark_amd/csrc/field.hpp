@@ -25,12 +25,54 @@ struct GL {
   static constexpr int EXT = 2;  // StarkField::Extension = GoldilocksFp2 (field.rs:38-41)
   static constexpr u64 NR2 = 7;
   static constexpr int MAX_DIGITS = 20;
-  // All operations take and return canonical values (< P).  They are written without compares / selects on purpose: on gfx950 a
-  // v_cmp_*_u64 + v_cndmask pair costs ~9 issue cycles and a trip through an SGPR pair, while the same decision made on the sign
-  // bits of the high words is one v_bitop3_b32 (2.7 cycles) and one arithmetic shift (rt.hpp: ms_bitop3 / ms_sar31).
+  // Compare + select formulation: the SHORTEST dependency chains (3-4 instructions deep), which is what the latency-bound kernels of
+  // the path (single-workgroup scans and reductions, the FRI tail) want.  The throughput-bound NTT tiles use GLT below.
   static MS_HD u32 hi(u64 x) { return (u32)(x >> 32); }
   static MS_HD u32 lo(u64 x) { return (u32)x; }
   static MS_HD u64 mk(u32 l, u32 h) { return ((u64)h << 32) | l; }
+  static MS_HD T add(T a, T b) {
+    const T s = a + b;
+    const T t = s - P;           // also the wrapped case: s + 2^64 - p == s - p (mod 2^64)
+    return (s < a || s >= P) ? t : s;
+  }
+  static MS_HD T sub(T a, T b) {
+    T d = a - b;
+    if (a < b) d -= EPS;         // wrapped: - 2^64 == - EPS (mod p)
+    return d;
+  }
+  static MS_HD T neg(T a) { return a ? P - a : 0; }
+  // 128-bit product folded with 2^64 == 2^32 - 1 and 2^96 == -1 (mod p)
+  static MS_HD T reduce128(u64 lo_, u64 hi_) {
+    const u64 hi_hi = hi_ >> 32, hi_lo = hi_ & EPS;
+    u64 t0 = lo_ - hi_hi;
+    t0 -= (lo_ < hi_hi) ? EPS : 0;         // borrow: - 2^64 == - EPS
+    const u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * EPS
+    const u64 r = t0 + t1;
+    const u64 r2 = r + EPS;                // r - p (mod 2^64): the fix for a carry AND for p <= r < 2^64
+    return (r < t1 || r >= P) ? r2 : r;
+  }
+  // 128-bit product as four 32x32+64 multiply-adds (v_mad_u64_u32): a*b and umul64hi separately cost two more multiplies
+  static MS_HD T mul(T a, T b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 p01 = (u64)a0 * b1 + (p00 >> 32);            // < 2^64: (2^32-1)^2 + 2^32 - 1
+    const u64 p10 = (u64)a1 * b0 + (u32)p01;
+    const u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    return reduce128((p10 << 32) | (u32)p00, p11);
+  }
+  static MS_HD T from_u64(u64 v) { return v; }
+  static MS_HD u64 to_u64(T v) { return v; }
+  // twiddle tables hold to_tw(w); mul_tw(a, to_tw(w)) == a * w.  Nothing to gain for Goldilocks: identity.
+  static MS_HD T to_tw(T w) { return w; }
+  static MS_HD T mul_tw(T a, T w_tab) { return mul(a, w_tab); }
+  static MS_HD T from_tw(T w_tab) { return w_tab; }
+};
+
+// Goldilocks, THROUGHPUT formulation (used by the NTT tiles): the same canonical results, decided on the sign bits of the high words
+// with v_bitop3_b32 instead of 64-bit compares and selects.  Measured on MI355X (tools/ntt_lab.hip): 5-13 % fewer issue cycles per
+// butterfly stage in a register-resident radix-16/32 network (11.7 instead of 12.6 VALU instructions per element-stage, no SGPR
+// round trips), but one instruction deeper per operation - slower in the latency-bound single-workgroup kernels, which keep GL.
+struct GLT : GL {
   static MS_HD u64 sel(u32 m, u64 t, u64 s) { return mk(ms_bitop3<0xCA>(m, lo(t), lo(s)), ms_bitop3<0xCA>(m, hi(t), hi(s))); }  // m ? t : s (m = 0 / ~0)
   static MS_HD T add(T a, T b) {
     const u64 s = a + b, t = s + EPS;                              // t = s - P (mod 2^64)
@@ -43,7 +85,6 @@ struct GL {
     const u32 bo = ms_bitop3<0x8E>(hi(a), hi(b), hi(d));           // bit 31: borrow out of a - b
     return d + ms_pin64(mk(bo >> 31, ms_sar31(bo)));               // + P on a borrow
   }
-  static MS_HD T neg(T a) { return a ? P - a : 0; }
   // A + h * 2^64 for h < 2^31  (2^64 == EPS): one multiply-add, the wrap / >= P decision on sign bits
   static MS_HD T fold_small(u64 A, u32 h) {
     const u64 r = (u64)h * 0xFFFFFFFFu + A, t = r + EPS;
@@ -87,12 +128,7 @@ struct GL {
     const u32 bo = ms_bitop3<0x0C>(hi(U), hi(r), 0u);              // wrapped iff U < z1 < 2^32
     return r + ms_pin64(mk(bo >> 31, ms_sar31(bo)));
   }
-  static MS_HD T from_u64(u64 v) { return v; }
-  static MS_HD u64 to_u64(T v) { return v; }
-  // twiddle tables hold to_tw(w); mul_tw(a, to_tw(w)) == a * w.  Nothing to gain for Goldilocks: identity.
-  static MS_HD T to_tw(T w) { return w; }
   static MS_HD T mul_tw(T a, T w_tab) { return mul(a, w_tab); }
-  static MS_HD T from_tw(T w_tab) { return w_tab; }
 };
 
 struct BB {

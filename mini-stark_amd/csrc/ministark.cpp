@@ -58,6 +58,9 @@ struct CtxBase {
   virtual int set_stream(void* s) = 0;
   virtual int synchronize() = 0;
   virtual int set_shard(int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) = 0;
+  virtual int set_shard_rccl(int rank, int world, const u8* unique_id, size_t cap) = 0;
+  virtual int shard_stats(u64* out) = 0;
+  virtual int rccl_selftest() = 0;
   virtual int trace_commit(const u64* trace, bool on_device, size_t N, size_t w, size_t lpn, u8* root) = 0;
   virtual int interpolate() = 0;
   virtual int polys_lincomb(const u64* s, const int* idx, int k) = 0;
@@ -109,15 +112,96 @@ template <class F> struct Ctx : CtxBase {
   u8* xs = nullptr; u8* xr = nullptr; size_t xcap = 0;   // caller-owned exchange buffers (device)
   ms_exchange_fn xfn = nullptr; void* xuser = nullptr;
   size_t shard_min_leaves = 32768;                        // MS_SHARD_MIN_LEAVES: smaller commitments stay replicated
+  void* rccl_comm = nullptr; DevBuf rccl_send, rccl_recv;   // ms_set_shard_rccl: the library owns the communicator and the exchange buffers
+  u64 xstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // calls per op [0..3], bytes sent per op [4..7] (ms_shard_stats)
   int exchange(int op, size_t bytes) {
+    xstat[op & 3]++; xstat[4 + (op & 3)] += (op == MS_XCHG_ALL_TO_ALL ? bytes * (size_t)(sh_world - 1) : bytes);
+    if (rccl_comm) {
+      // RCCL on the context's stream: stream-ordered with the kernels on both sides, no host synchronisation, no host callback
+      msrt::Rccl& R = msrt::Rccl::get();
+      const int W = sh_world;
+      int e = 0;
+      if (op == MS_XCHG_ALL_TO_ALL) {
+        e = R.group_start();
+        for (int r = 0; r < W && !e; r++) {
+          e = R.send(xs + (size_t)r * bytes, bytes, 1 /* ncclUint8 */, r, rccl_comm, stream);
+          if (!e) e = R.recv(xr + (size_t)r * bytes, bytes, 1, r, rccl_comm, stream);
+        }
+        const int e2 = R.group_end();
+        if (!e) e = e2;
+      } else if (op == MS_XCHG_ALL_GATHER) e = R.all_gather(xs, xr, bytes, 1, rccl_comm, stream);
+      else if (op == MS_XCHG_ALL_REDUCE_MIN_U64) e = R.all_reduce(xs, xs, bytes / 8, 5 /* ncclUint64 */, 3 /* ncclMin */, rccl_comm, stream);
+      else e = R.all_reduce(xs, xs, bytes, 1, 0 /* ncclSum */, rccl_comm, stream);
+      if (e) { err = std::string("RCCL error ") + std::to_string(e) + (R.err_string ? std::string(": ") + R.err_string(e) : std::string()); return MS_ERR_HIP; }
+      return 0;
+    }
     CK(msrt::sync(stream));
     if (xfn(xuser, op, bytes)) return fail(MS_ERR_HIP, "exchange callback failed");
     return 0;
   }
+  void drop_rccl() {
+    if (rccl_comm) { msrt::sync(stream); msrt::Rccl::get().comm_destroy(rccl_comm); rccl_comm = nullptr; }
+    rccl_send.release(); rccl_recv.release();
+  }
+  int set_shard_rccl(int rank, int world, const u8* unique_id, size_t cap) override {
+    if (world < 1 || !is_pow2((u64)world) || rank < 0 || rank >= world) return fail(MS_ERR_ARG, "set_shard_rccl: world must be a power of two and 0 <= rank < world");
+    drop_rccl();
+    if (world == 1) return set_shard(0, 1, nullptr, nullptr, 0, nullptr, nullptr);
+    if (!unique_id || cap < 4096) return fail(MS_ERR_ARG, "set_shard_rccl: unique id / buffer capacity missing");
+    msrt::Rccl& R = msrt::Rccl::get();
+    if (R.load()) return fail(MS_ERR_HIP, "RCCL is not available (librccl.so could not be loaded; MS_RCCL_LIB names it)");
+    if (rccl_send.ensure(cap) || rccl_recv.ensure(cap)) return fail(MS_ERR_NOMEM, "exchange buffers");
+    msrt::Rccl::UniqueId id; memcpy(id.internal, unique_id, sizeof id.internal);
+    void* comm = nullptr;
+    const int e = R.comm_init_rank(&comm, world, id, rank);
+    if (e || !comm) { err = std::string("ncclCommInitRank failed: ") + (R.err_string ? R.err_string(e) : "?"); return MS_ERR_HIP; }
+    rccl_comm = comm;
+    sh_rank = rank; sh_world = world; xs = rccl_send.as<u8>(); xr = rccl_recv.as<u8>(); xcap = cap; xfn = nullptr; xuser = nullptr;
+    have_lde = false; nrounds_done = 0; blob_size = 0;
+    return MS_OK;
+  }
+  // The four collectives on a one-rank communicator (send/recv to self, all-gather, both all-reduces) with known payloads:
+  // checks the run-time binding of librccl.so (symbols, calling convention of the by-value ncclUniqueId, datatype / op enums)
+  // and the stream ordering on a box with a single GPU.
+  int rccl_selftest() override {
+    msrt::Rccl& R = msrt::Rccl::get();
+    if (R.load()) return fail(MS_ERR_HIP, "RCCL is not available (librccl.so could not be loaded; MS_RCCL_LIB names it)");
+    msrt::Rccl::UniqueId id;
+    if (R.get_unique_id(&id)) return fail(MS_ERR_HIP, "ncclGetUniqueId failed");
+    void* comm = nullptr;
+    int e = R.comm_init_rank(&comm, 1, id, 0);
+    if (e || !comm) return fail(MS_ERR_HIP, "ncclCommInitRank(1 rank) failed");
+    DevBuf a, b;
+    int rc = MS_OK;
+    if (a.ensure(4096) || b.ensure(4096)) rc = fail(MS_ERR_NOMEM, "selftest buffers");
+    u64 h[64], g[64];
+    for (int i = 0; i < 64; i++) h[i] = 0x0123456789ABCDEFull * (u64)(i + 1);
+    if (!rc && (msrt::h2d(a.p, h, sizeof h, stream) || msrt::memset_dev(b.p, 0, 4096, stream))) rc = fail(MS_ERR_HIP, "selftest upload");
+    if (!rc) {
+      e = R.group_start();
+      if (!e) e = R.send(a.p, 256, 1, 0, comm, stream);
+      if (!e) e = R.recv(b.p, 256, 1, 0, comm, stream);
+      const int e2 = R.group_end(); if (!e) e = e2;
+      if (!e) e = R.all_gather(a.as<u8>() + 256, b.as<u8>() + 256, 128, 1, comm, stream);
+      if (!e) e = R.all_reduce(a.p, a.p, 8, 5, 3, comm, stream);        // MIN over one rank: unchanged
+      if (!e) e = R.all_reduce(a.p, a.p, 64, 1, 0, comm, stream);       // SUM over one rank: unchanged
+      if (e) rc = fail(MS_ERR_HIP, "RCCL collective failed in the self test");
+    }
+    if (!rc && (msrt::d2h(g, b.p, sizeof g, stream) || msrt::sync(stream))) rc = fail(MS_ERR_HIP, "selftest download");
+    if (!rc) for (int i = 0; i < 48; i++) if (g[i] != h[i]) { rc = fail(MS_ERR_HIP, "RCCL self test: payload mismatch"); break; }
+    if (!rc && (msrt::d2h(g, a.p, sizeof g, stream) || msrt::sync(stream))) rc = fail(MS_ERR_HIP, "selftest download");
+    if (!rc) for (int i = 0; i < 64; i++) if (g[i] != h[i]) { rc = fail(MS_ERR_HIP, "RCCL self test: all-reduce changed a one-rank payload"); break; }
+    msrt::sync(stream);
+    R.comm_destroy(comm);
+    a.release(); b.release();
+    return rc;
+  }
+  int shard_stats(u64* out) override { if (!out) return fail(MS_ERR_ARG, "shard_stats"); memcpy(out, xstat, sizeof xstat); return MS_OK; }
   bool shardable(size_t leaf_groups) const { return sh_world > 1 && leaf_groups >= shard_min_leaves && leaf_groups >= (size_t)sh_world * (size_t)sh_world; }
   int set_shard(int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) override {
     if (world < 1 || !is_pow2((u64)world) || rank < 0 || rank >= world) return fail(MS_ERR_ARG, "set_shard: world must be a power of two and 0 <= rank < world");
     if (world > 1 && (!d_send || !d_recv || !fn || cap < 4096)) return fail(MS_ERR_ARG, "set_shard: exchange buffers / callback missing");
+    drop_rccl();
     sh_rank = rank; sh_world = world; xs = reinterpret_cast<u8*>(d_send); xr = reinterpret_cast<u8*>(d_recv); xcap = cap; xfn = fn; xuser = user;
     have_lde = false; nrounds_done = 0; blob_size = 0;
     return MS_OK;
@@ -576,6 +660,7 @@ template <class F> struct Ctx : CtxBase {
   }
   ~Ctx() {
     for (auto& kv : plans) { kv.second->tw_lo.release(); kv.second->tw_hi.release(); kv.second->vtw.release(); kv.second->w0.release(); for (auto& b : kv.second->w_r) b.release(); delete kv.second; }
+    drop_rccl();
     for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
     DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero};
     for (DevBuf* b : bufs) b->release();
@@ -1397,6 +1482,22 @@ int ms_set_shard(ms_ctx* ctx, int rank, int world, void* d_send, void* d_recv, s
   B(ctx)->bind_device();
   return B(ctx)->set_shard(rank, world, d_send, d_recv, cap, fn, user);
 }
+int ms_rccl_unique_id(uint8_t out[128]) {
+  if (!out) return MS_ERR_ARG;
+  msrt::Rccl& R = msrt::Rccl::get();
+  if (R.load()) return MS_ERR_HIP;
+  msrt::Rccl::UniqueId id;
+  if (R.get_unique_id(&id)) return MS_ERR_HIP;
+  memcpy(out, id.internal, 128);
+  return MS_OK;
+}
+int ms_set_shard_rccl(ms_ctx* ctx, int rank, int world, const uint8_t unique_id[128], size_t cap_bytes) {
+  if (!ctx) return MS_ERR_ARG;
+  B(ctx)->bind_device();
+  return B(ctx)->set_shard_rccl(rank, world, unique_id, cap_bytes);
+}
+int ms_rccl_selftest(ms_ctx* ctx) { if (!ctx) return MS_ERR_ARG; B(ctx)->bind_device(); return B(ctx)->rccl_selftest(); }
+int ms_shard_stats(ms_ctx* ctx, uint64_t out[8]) { if (!ctx) return MS_ERR_ARG; return B(ctx)->shard_stats(out); }
 int ms_synchronize(ms_ctx* ctx) { if (!ctx) return MS_ERR_ARG; B(ctx)->bind_device(); return B(ctx)->synchronize(); }
 
 int ms_is_power_of_two(uint64_t n) { return is_pow2(n) ? 1 : 0; }

@@ -72,12 +72,27 @@ template <class F> struct PassParams {
 
 // ---- Goldilocks shift twiddles ------------------------------------------------
 // x * 2^S mod p for a compile-time S in [0, 96)
+// round-1 formulation (compare + select reduce128), used by the round-1 tiles (arithmetic class GL)
+template <int S> MS_HD u64 gl_mul_pow2_v1(u64 x) {
+  static_assert(S >= 0 && S < 96, "shift out of range");
+  if constexpr (S == 0) return x;
+  else if constexpr (S < 64) return GL::reduce128(x << S, x >> (64 - S));
+  else {  // x*2^S == x*2^(S-32) - x*2^(S-64)  (2^64 == 2^32 - 1)
+    constexpr int A = S - 32, B = S - 64;  // 32 <= A < 64, 0 <= B < 32
+    const u64 alo = x << A, ahi = x >> (64 - A);
+    const u64 blo = x << B, bhi = (B == 0) ? 0 : (x >> ((64 - B) & 63));
+    const u64 lo = alo - blo;
+    const u64 hi = ahi - bhi - (alo < blo ? 1 : 0);
+    return GL::reduce128(lo, hi);
+  }
+}
+// throughput formulation (arithmetic class GLT): every step canonical and branch-free on sign bits
 template <int S> MS_HD u64 gl_mul_pow2(u64 x) {
   static_assert(S >= 0 && S < 96, "shift out of range");
   if constexpr (S == 0) return x;
-  else if constexpr (S < 32) return GL::fold_small(ms_pin64(x << S), GL::hi(x) >> (32 - S));  // the S bits shifted out times 2^64 == EPS (pinned: one v_lshlrev_b64, its high word reused)
-  else if constexpr (S < 64) return GL::mul_x32(gl_mul_pow2<S - 32>(x));            // two steps: both stay canonical and branch-free
-  else return GL::mul_x64(gl_mul_pow2<S - 64>(x));
+  else if constexpr (S < 32) return GLT::fold_small(ms_pin64(x << S), GL::hi(x) >> (32 - S));  // the S bits shifted out times 2^64 == EPS (pinned: one v_lshlrev_b64, its high word reused)
+  else if constexpr (S < 64) return GLT::mul_x32(gl_mul_pow2<S - 32>(x));                       // two steps: both stay canonical
+  else return GLT::mul_x64(gl_mul_pow2<S - 64>(x));
 }
 // (a - b) * w_(2^LOG2H2)^J for the reference's roots: w_64 = 2^39 (forward), 2^153 (inverse)
 template <class F, bool INV, int LOG2H2, int J> struct TwMul;
@@ -85,13 +100,29 @@ template <bool INV, int LOG2H2, int J> struct TwMul<GL, INV, LOG2H2, J> {
   static constexpr int EXP = ((INV ? 153 : 39) * (64 >> LOG2H2) * J) % 192;
   static MS_HD u64 diff_mul(u64 a, u64 b, const u64* w_r, int log_r) {
     (void)w_r; (void)log_r;
-    if constexpr (EXP >= 96) return gl_mul_pow2<EXP - 96>(GL::sub(b, a));  // 2^96 == -1
-    else return gl_mul_pow2<EXP>(GL::sub(a, b));
+    if constexpr (EXP >= 96) return gl_mul_pow2_v1<EXP - 96>(GL::sub(b, a));  // 2^96 == -1
+    else return gl_mul_pow2_v1<EXP>(GL::sub(a, b));
+  }
+};
+template <bool INV, int LOG2H2, int J> struct TwMul<GLT, INV, LOG2H2, J> {
+  static constexpr int EXP = ((INV ? 153 : 39) * (64 >> LOG2H2) * J) % 192;
+  static MS_HD u64 diff_mul(u64 a, u64 b, const u64* w_r, int log_r) {
+    (void)w_r; (void)log_r;
+    if constexpr (EXP >= 96) return gl_mul_pow2<EXP - 96>(GLT::sub(b, a));
+    else return gl_mul_pow2<EXP>(GLT::sub(a, b));
   }
 };
 template <bool INV, int LOG2H2, int J> struct TwMul<BB, INV, LOG2H2, J> {
   static MS_HD u32 diff_mul(u32 a, u32 b, const u32* w_r, int log_r) { return BB::mul_tw(BB::sub(a, b), w_r[(size_t)J << (log_r - LOG2H2)]); }
 };
+// arithmetic class of the round-2 tiles: the throughput formulation where the field has one
+template <class F> struct NttArith { typedef F type; };
+#ifndef MS_NTT_GLT
+#define MS_NTT_GLT 1
+#endif
+#if MS_NTT_GLT
+template <> struct NttArith<GL> { typedef GLT type; };
+#endif
 
 template <class F, bool INV, int B, int S, int BLK, int J> struct DifStage {
   // butterflies of stage S (distance 2^S) inside a 2^B-point DIF, unrolled at compile time
@@ -413,6 +444,7 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
 //                              coefficient index, the tile's output is one contiguous block of r0 * r elements
 template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
   typedef typename F::T T;
+  typedef typename NttArith<F>::type A;   // arithmetic class (same values as F's, formulated for throughput)
   typedef PassParams<F> Params;
   static constexpr int THREADS = TH;
   static constexpr int R = 1 << K, C = 1 << LC;
@@ -435,7 +467,7 @@ template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
   static MS_DEV T tw_global(const Params& p, size_t e) {
     T tw = p.tw_lo[e & (((size_t)1 << p.lo_bits) - 1)];
     const size_t eh = e >> p.lo_bits;
-    if (eh) tw = F::mul_tw(tw, p.tw_hi[eh]);
+    if (eh) tw = A::mul_tw(tw, p.tw_hi[eh]);
     return tw;
   }
   // logical tile of workgroup bx.  Behind the virtual pass the 2^LC... tiles that share 64-byte source lines are neighbours: give each
@@ -455,11 +487,11 @@ template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
       T x[1 << B];
 #pragma unroll
       for (int t = 0; t < (1 << B); t++) x[t] = base[t * (Q1 * C + PADE)];
-      dif_regs<F, INV, B>(x, w, K);
+      dif_regs<A, INV, B>(x, w, K);
 #pragma unroll
       for (int e = 0; e < (1 << B); e++) {
         T v = x[bitrev(e, B)];
-        if (e != 0) v = F::mul_tw(v, w[e * lo]);              // w_r^(e * lo); lo == 0 multiplies by w[0] = 1
+        if (e != 0) v = A::mul_tw(v, w[e * lo]);              // w_r^(e * lo); lo == 0 multiplies by w[0] = 1
         base[e * (Q1 * C + PADE)] = v;
       }
     }
@@ -474,7 +506,7 @@ template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
       T x[1 << B];
 #pragma unroll
       for (int t = 0; t < (1 << B); t++) x[t] = base[t * C];
-      dif_regs<F, INV, B>(x, w, K);
+      dif_regs<A, INV, B>(x, w, K);
 #pragma unroll
       for (int e = 0; e < (1 << B); e++) base[e * C] = x[bitrev(e, B)];
     }
@@ -516,7 +548,7 @@ template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
           const int row = idx >> LC, i1 = idx & (C - 1);
           const size_t k = k2 + nprime * (size_t)row;
           T v = (k < p.n_in) ? src[k] : (T)0;
-          if (i1) v = F::mul_tw(v, p.vtw[(size_t)i1 * row]);
+          if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
           tile[tix(row, i1)] = v;
         }
       }
@@ -558,9 +590,9 @@ template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
           T x = sp[v];
-          if (row_tw) x = F::mul_tw(x, rt);
-          if (col_tw && (c0 + v)) x = F::mul_tw(x, gc[v]);
-          if (do_scale) x = F::mul_tw(x, p.scale);
+          if (row_tw) x = A::mul_tw(x, rt);
+          if (col_tw && (c0 + v)) x = A::mul_tw(x, gc[v]);
+          if (do_scale) x = A::mul_tw(x, p.scale);
           o.v[v] = x;
         }
         *reinterpret_cast<V16*>(out + ((size_t)inew << p.log_Rp)) = o;
@@ -576,8 +608,8 @@ template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
           const int inew = inew0 + v;
           const int row = ((inew & ((1 << B1) - 1)) << B2) | (inew >> B1);
           T x = tile[tix(row, c)];
-          if (!p.last) { const size_t e = (size_t)inew * f; if (e) x = F::mul_tw(x, tw_global(p, e)); }
-          if (do_scale) x = F::mul_tw(x, p.scale);
+          if (!p.last) { const size_t e = (size_t)inew * f; if (e) x = A::mul_tw(x, tw_global(p, e)); }
+          if (do_scale) x = A::mul_tw(x, p.scale);
           o.v[v] = x;
         }
         *reinterpret_cast<V16*>(dst + (f << K) + inew0) = o;

@@ -54,6 +54,18 @@ inline int launch(Stream*, unsigned gx, unsigned gy, int threads, size_t lds_byt
         for (int t = 0; t < threads; t++) K::phase(ph, p, (int)bx, (int)by, t, threads, lds.data());
   return 0;
 }
+// no RCCL in the emulation build: ms_set_shard_rccl reports MS_ERR_HIP, the gloo tests use the exchange callback
+struct Rccl {
+  struct UniqueId { char internal[128]; };
+  void* lib = nullptr;
+  int (*get_unique_id)(void*) = nullptr; int (*comm_init_rank)(void**, int, UniqueId, int) = nullptr; int (*comm_destroy)(void*) = nullptr;
+  int (*group_start)() = nullptr; int (*group_end)() = nullptr;
+  int (*send)(void*, size_t, int, int, void*, Stream*) = nullptr; int (*recv)(void*, size_t, int, int, void*, Stream*) = nullptr;
+  int (*all_gather)(const void*, void*, size_t, int, void*, Stream*) = nullptr; int (*all_reduce)(const void*, void*, size_t, int, int, void*, Stream*) = nullptr;
+  const char* (*err_string)(int) = nullptr;
+  static Rccl& get() { static Rccl r; return r; }
+  int load() { return 1; }
+};
 MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { if (v < *a) *a = v; }
 MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { if (v > *a) *a = v; }
 MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { unsigned o = *a; *a = o + v; return o; }
@@ -89,6 +101,49 @@ inline int event_create(Event** e) { return (int)hipEventCreate(e); }
 inline int event_destroy(Event* e) { return (int)hipEventDestroy(e); }
 inline int event_record(Event* e, Stream* s) { return (int)hipEventRecord(e, s); }
 inline int event_elapsed_ms(float* ms, Event* a, Event* b) { return (int)hipEventElapsedTime(ms, a, b); }
+
+// ---- RCCL, bound at run time (dlopen: the library neither links against nor requires librccl unless ms_set_shard_rccl is used).
+// Only the handful of entry points the sharded proof needs; types restated from <rccl/rccl.h> (ncclUniqueId = 128 opaque bytes,
+// ncclUint8 = 1, ncclUint64 = 5, ncclSum = 0, ncclMin = 3, ncclSuccess = 0).
+struct Rccl {
+  typedef int (*GetUniqueIdFn)(void*);
+  typedef int (*CommInitRankFn)(void**, int, const void* /* ncclUniqueId by value, see init_rank */, int);
+  typedef int (*CommDestroyFn)(void*);
+  typedef int (*GroupFn)();
+  typedef int (*SendRecvFn)(void*, size_t, int, int, void*, Stream*);
+  typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, Stream*);
+  typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, void*, Stream*);
+  typedef const char* (*ErrStrFn)(int);
+  struct UniqueId { char internal[128]; };
+  void* lib = nullptr;
+  GetUniqueIdFn get_unique_id = nullptr; int (*comm_init_rank)(void**, int, UniqueId, int) = nullptr; CommDestroyFn comm_destroy = nullptr;
+  GroupFn group_start = nullptr, group_end = nullptr; SendRecvFn send = nullptr, recv = nullptr; AllGatherFn all_gather = nullptr; AllReduceFn all_reduce = nullptr;
+  ErrStrFn err_string = nullptr;
+  static Rccl& get() { static Rccl r; return r; }
+  // 0 on success.  MS_RCCL_LIB names the library (default: the RCCL already mapped into the process, e.g. PyTorch's, else librccl.so)
+  int load();
+};
+}  // namespace msrt
+#include <dlfcn.h>
+namespace msrt {
+inline int Rccl::load() {
+  if (lib) return 0;
+  const char* names[] = {getenv("MS_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* n : names) { if (n && *n) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; } }
+  if (!h) return 1;
+  auto sym = [&](const char* n) { return dlsym(h, n); };
+  get_unique_id = (GetUniqueIdFn)sym("ncclGetUniqueId");
+  comm_init_rank = (int (*)(void**, int, UniqueId, int))sym("ncclCommInitRank");
+  comm_destroy = (CommDestroyFn)sym("ncclCommDestroy");
+  group_start = (GroupFn)sym("ncclGroupStart"); group_end = (GroupFn)sym("ncclGroupEnd");
+  send = (SendRecvFn)sym("ncclSend"); recv = (SendRecvFn)sym("ncclRecv");
+  all_gather = (AllGatherFn)sym("ncclAllGather"); all_reduce = (AllReduceFn)sym("ncclAllReduce");
+  err_string = (ErrStrFn)sym("ncclGetErrorString");
+  if (!get_unique_id || !comm_init_rank || !comm_destroy || !group_start || !group_end || !send || !recv || !all_gather || !all_reduce) { dlclose(h); return 2; }
+  lib = h;
+  return 0;
+}
 
 // optional K::MIN_WAVES = minimum waves per SIMD the register allocator must leave room for
 template <class K, class = void> struct MinWaves { static constexpr int v = 1; };

@@ -62,6 +62,32 @@ class Group:
             self.dist.destroy_process_group()
 
 
+class RcclShard:
+    """One proof sharded over the ranks with the collectives INSIDE the library (ms_set_shard_rccl): rank 0's ncclUniqueId is
+    broadcast with torch.distributed, every rank joins the library's own RCCL communicator; after that no Python runs in the loop."""
+
+    def __init__(self, group: Group, ctx, cap_bytes: int):
+        self.g, self.ctx = group, ctx
+        uid = ctx.rccl_unique_id() if group.rank == 0 else bytes(128)
+        if group.dist is not None:
+            t = torch.frombuffer(bytearray(uid), dtype=torch.uint8).to(group.device)
+            group.dist.broadcast(t, src=0)
+            uid = bytes(t.cpu().numpy().tobytes())
+        ctx.set_shard_rccl(group.rank, group.world, uid, cap_bytes)
+
+    @property
+    def calls(self):
+        st = self.ctx.shard_stats()
+        return {i: st[i] for i in range(4)}
+
+    @property
+    def bytes(self):
+        return sum(self.ctx.shard_stats()[4:8])
+
+    def close(self):
+        self.ctx.set_shard_rccl(0, 1, bytes(128), 0)
+
+
 class ShardExchange:
     """The exchange callback of ms_set_shard over torch.distributed.
 

@@ -20,8 +20,9 @@ def host_library_path():
 
 def build_host_library(force=False):
     so, src = host_library_path(), os.path.join(_HERE, "host", "stark_host.cpp")
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "ministark.h")
-    if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    deps = [src, os.path.join(inc, "ministark.h"), os.path.join(inc, "ministark_host.h"), os.path.join(_HERE, "csrc", "field.hpp"), os.path.join(_HERE, "csrc", "rt.hpp")]
+    if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
         return so
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
     return so
@@ -35,7 +36,7 @@ def _host():
             raise MsError(-6, f"{path} not found: run __graft_entry__.build()")
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)
         L.msh_stark_new.restype = C.c_void_p
-        for n in ("msh_proof_arthur", "msh_proof_evals", "msh_proof_fri_roots", "msh_proof_fri_blob", "msh_proof_challenges", "msh_proof_num_polys"):
+        for n in ("msh_proof_arthur", "msh_proof_evals", "msh_proof_fri_roots", "msh_proof_fri_blob", "msh_proof_challenges", "msh_proof_num_polys", "msh_proof_serialize"):
             getattr(L, n).restype = C.c_size_t
         _HOST = L
     return _HOST
@@ -135,6 +136,38 @@ class HostStark:
             raise MsError(rc, self.last_verify_error)
         return rc == 1
 
+    def proof_bytes(self) -> bytes:
+        """msh_proof_serialize: the last proof in the MSSP wire format (include/ministark_host.h), written by the C++ mirror."""
+        n = self.H.msh_proof_serialize(self.h, None, C.c_size_t(0))
+        if n == 0:
+            raise MsError(-4, "no proof to serialise (none proved yet, or its FRI proof was left in HBM)")
+        buf = (C.c_uint8 * n)()
+        assert self.H.msh_proof_serialize(self.h, buf, C.c_size_t(n)) == n
+        return bytes(buf)
+
+    def verify_bytes(self, constrains, data: bytes, zero_display_empty=True) -> bool:
+        """msh_stark_verify_mssp: Stark::verify straight from the wire format."""
+        cs = np.ascontiguousarray(constrains, dtype=np.uint64)
+        c, N = cs.shape
+        why = C.create_string_buffer(512)
+        self.H.msh_stark_verify_mssp.restype = C.c_int
+        rc = self.H.msh_stark_verify_mssp(self.h, cs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(c), C.c_size_t(N), data, C.c_size_t(len(data)),
+                                          C.c_int(1 if zero_display_empty else 0), why, C.c_size_t(512))
+        self.last_verify_error = why.value.decode()
+        if rc < 0:
+            raise MsError(rc, self.last_verify_error)
+        return rc == 1
+
     def prove(self, trace, trace_device_ptr=None, read_fri_proof=True) -> StarkProof:
         self.ctx.check(self.prove_raw(trace, trace_device_ptr, read_fri_proof))
         return self.last_proof(read_fri_proof)
+
+
+def fibonacci_rows_native(p, length, steps, secret_b=2, pad_seed=0x5EED):
+    """msh_fibonacci_rows: the benchmark's synthetic trace in C (same values as mini_stark_amd.synthetic.fibonacci_rows; the Python
+    loop takes ~1 us per row, 16 s at 2^24 rows)."""
+    out = np.empty((length, 3), dtype=np.uint64)
+    rc = _host().msh_fibonacci_rows(C.c_uint64(p), C.c_size_t(length), C.c_size_t(steps), C.c_uint64(secret_b), C.c_uint64(pad_seed), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc != 0:
+        raise MsError(rc, "msh_fibonacci_rows")
+    return out

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/ministark.h"
+#include "../../include/ministark_host.h"
 #define MS_HOST_ONLY 1
 #include "../csrc/field.hpp"  // Goldilocks / BabyBear arithmetic for the CPU verifier (typedefs u64, u32, u8)
 
@@ -389,5 +390,72 @@ int msh_stark_verify(const msh_stark* h, const u64* constrains, size_t c, size_t
   else rc = Verifier<BB, 4>::run(h->s.cfg, constrains, c, N, pr, zero_display_empty, &reason);
   if (why && why_cap) { size_t n = reason.size() < why_cap - 1 ? reason.size() : why_cap - 1; memcpy(why, reason.data(), n); why[n] = 0; }
   return rc;
+}
+// ---- whole-proof wire format "MSSP" v1 (layout in include/ministark_host.h) ----------------------------
+static const size_t MSSP_HEAD = 4 + 5 * 4 + 2 * 8;
+// bytes needed for the last proof of `h` (0: no proof, or its FRI proof was left in HBM); writes them when cap suffices
+size_t msh_proof_serialize(const msh_stark* h, u8* out, size_t cap) {
+  const StarkProof& pr = h->s.proof; const StarkConfig& c = h->s.cfg;
+  if (pr.arthur.empty() || pr.fri_blob.empty()) return 0;
+  const u32 e = (u32)c.e, cc = (u32)pr.c, q = (u32)c.constrain_queries, rounds = (u32)(pr.fri_roots.size() / 32);
+  const size_t need = MSSP_HEAD + 64 + pr.evals.size() * 8 + pr.fri_roots.size() + pr.arthur.size() + pr.fri_blob.size();
+  if (!out || cap < need) return need;
+  u8* w = out;
+  auto put = [&](const void* d, size_t n) { memcpy(w, d, n); w += n; };
+  const u32 ver = 1; const u64 la = pr.arthur.size(), lb = pr.fri_blob.size();
+  put("MSSP", 4); put(&ver, 4); put(&e, 4); put(&cc, 4); put(&q, 4); put(&rounds, 4); put(&la, 8); put(&lb, 8);
+  put(pr.trace_commit, 32); put(pr.constrain_trace_commit, 32);
+  // evals are stored [q][c+1][E] (constrain queries then the validity query per point); the wire order is all constrain queries, then all validity queries
+  for (u32 i = 0; i < q; i++) put(pr.evals.data() + (size_t)i * (cc + 1) * e, (size_t)cc * e * 8);
+  for (u32 i = 0; i < q; i++) put(pr.evals.data() + ((size_t)i * (cc + 1) + cc) * e, (size_t)e * 8);
+  put(pr.fri_roots.data(), pr.fri_roots.size()); put(pr.arthur.data(), la); put(pr.fri_blob.data(), lb);
+  return need;
+}
+// parses an MSSP blob: 0 on success (fields of `v` point INTO `data`), -1 malformed
+int msh_proof_parse(const u8* data, size_t len, msh_proof_view* v) {
+  if (!data || !v || len < MSSP_HEAD + 64 || memcmp(data, "MSSP", 4) != 0) return -1;
+  u32 ver; memcpy(&ver, data + 4, 4); if (ver != 1) return -1;
+  memcpy(&v->e, data + 8, 4); memcpy(&v->c, data + 12, 4); memcpy(&v->q, data + 16, 4); memcpy(&v->rounds, data + 20, 4);
+  memcpy(&v->arthur_len, data + 24, 8); memcpy(&v->fri_blob_len, data + 32, 8);
+  const size_t ev = (size_t)v->q * (v->c + 1) * v->e * 8;
+  const size_t need = MSSP_HEAD + 64 + ev + (size_t)v->rounds * 32 + v->arthur_len + v->fri_blob_len;
+  if (need != len) return -1;
+  const u8* p = data + MSSP_HEAD;
+  v->trace_commit = p; v->constrain_trace_commit = p + 32; p += 64;
+  v->constrain_queries = (const u64*)p; p += (size_t)v->q * v->c * v->e * 8;
+  v->validity_queries = (const u64*)p; p += (size_t)v->q * v->e * 8;
+  v->fri_roots = p; p += (size_t)v->rounds * 32;
+  v->arthur = p; p += v->arthur_len;
+  v->fri_blob = p;
+  return 0;
+}
+// Stark::verify straight from the wire format: 1 accepted, 0 rejected, < 0 malformed
+int msh_stark_verify_mssp(const msh_stark* h, const u64* constrains, size_t c, size_t N, const u8* data, size_t len, int zero_display_empty, char* why, size_t why_cap) {
+  msh_proof_view v;
+  if (msh_proof_parse(data, len, &v) || v.c != c || (int)v.e != h->s.cfg.e) { if (why && why_cap) { strncpy(why, "malformed MSSP proof", why_cap - 1); why[why_cap - 1] = 0; } return -1; }
+  std::vector<u64> evals((size_t)v.q * (v.c + 1) * v.e);
+  for (u32 i = 0; i < v.q; i++) {
+    memcpy(evals.data() + (size_t)i * (v.c + 1) * v.e, v.constrain_queries + (size_t)i * v.c * v.e, (size_t)v.c * v.e * 8);
+    memcpy(evals.data() + ((size_t)i * (v.c + 1) + v.c) * v.e, v.validity_queries + (size_t)i * v.e, (size_t)v.e * 8);
+  }
+  return msh_stark_verify(h, constrains, c, N, v.arthur, v.arthur_len, v.trace_commit, v.constrain_trace_commit, evals.data(), evals.size(), v.fri_roots, v.rounds,
+                          v.fri_blob, v.fri_blob_len, zero_display_empty, why, why_cap);
+}
+// the synthetic Fibonacci-AIR trace of the benchmark workload (tests/e2e_goldilocks.rs:20-63 rows + SplitMix64 padding; = mini_stark_amd.synthetic.fibonacci_rows)
+int msh_fibonacci_rows(u64 p, size_t length, size_t steps, u64 secret_b, u64 pad_seed, u64* out) {
+  if (!out || steps > length || p < 2) return -1;
+  u64 a = 1 % p, b = secret_b % p;
+  for (size_t i = 0; i < steps; i++) {
+    const u64 cc = (u64)(((unsigned __int128)a + b) % p);
+    out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = cc;
+    a = b; b = cc;
+  }
+  u64 sm = pad_seed;
+  for (size_t i = 3 * steps; i < 3 * length; i++) {
+    sm += 0x9E3779B97F4A7C15ULL; u64 z = sm;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
+    out[i] = z % p;
+  }
+  return 0;
 }
 }

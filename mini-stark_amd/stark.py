@@ -33,15 +33,18 @@ class Transcript:
     def __init__(self, domsep: str):
         self.state = hashlib.sha256(b"mini-stark_amd/transcript/v0" + domsep.encode()).digest()
         self.prover_bytes = bytearray()  # what nimue calls the transcript ("arthur", starks.rs:160)
+        self.ops = []                    # ("absorb", nbytes) / ("squeeze", nbytes): the IOPattern the reference declares (fiatshamir.rs:48-64,100-116)
 
     def add_bytes(self, data: bytes):
+        self.ops.append(("absorb", len(data)))
         self.prover_bytes += data
         self.state = hashlib.sha256(self.state + b"A" + data).digest()
 
     def add_scalars(self, limbs):
         self.add_bytes(b"".join(struct.pack("<Q", int(v)) for v in limbs))
 
-    def challenge_bytes(self, n: int) -> bytes:
+    def challenge_bytes(self, n: int, _scalars=None) -> bytes:
+        self.ops.append(("squeeze_scalars", _scalars) if _scalars is not None else ("squeeze_bytes", n))
         out = b""
         ctr = 0
         while len(out) < n:
@@ -51,7 +54,7 @@ class Transcript:
         return out[:n]
 
     def challenge_scalars(self, count: int, p: int):
-        raw = self.challenge_bytes(16 * count)
+        raw = self.challenge_bytes(16 * count, _scalars=count)
         return [int.from_bytes(raw[16 * i:16 * i + 16], "little") % p for i in range(count)]
 
 
@@ -195,16 +198,24 @@ class Stark:
         rc, blob = ctx.fri_query(betas, read=read_fri_proof)
         ctx.check(rc)
         self.last_challenges = dict(shift=shift, r=r, z=z, betas=betas)
+        self.last_transcript_ops = list(t.ops)
         return StarkProof(bytes(t.prover_bytes), trace_commit, lde_commit, ev[:, :c, :], ev[:, c, :],
                           FriProof(blob or b"", device_resident=not read_fri_proof), roots)
 
 
 def fibonacci_air(ctx: Context, steps: int, secret_b: int = 2, pad_seed: int = 0x5EED) -> TraceTable:
     """The Fibonacci AIR of tests/e2e_goldilocks.rs:20-63 (w = 3, three transition closures)."""
-    from .synthetic import fibonacci_rows
     p = _MODULUS[ctx.field]
     tt = TraceTable(ctx, steps, 3)
-    tt.data[:] = fibonacci_rows(p, tt.length, steps, secret_b, pad_seed)
+    try:   # C helper of the host mirror (16 s -> 0.1 s at 2^24 rows); same values as synthetic.fibonacci_rows (tests/test_host_mirror.py)
+        from .host import fibonacci_rows_native, host_library_path
+        import os
+        if not os.path.exists(host_library_path()):
+            raise ImportError
+        tt.data[:] = fibonacci_rows_native(p, tt.length, steps, secret_b, pad_seed)
+    except (ImportError, OSError):
+        from .synthetic import fibonacci_rows
+        tt.data[:] = fibonacci_rows(p, tt.length, steps, secret_b, pad_seed)
     m1 = p - 1
     tt.add_transition_lincomb([tt.omega, m1], [0, 1])      # e2e_goldilocks.rs:48-51
     tt.add_transition_lincomb([tt.omega, m1], [0, 1])      # e2e_goldilocks.rs:53-56 (identical, quirk Q2)

@@ -33,3 +33,15 @@ def test_no_fallback_when_library_missing(tmp_path):
     import pytest
     with pytest.raises(ms.MsError):
         ms.Context(ms.GOLDILOCKS, lib_path=str(tmp_path / "nope.so"))
+
+
+def test_host_library_exports_its_header():
+    """libministark_host.so (the host mirror above the C ABI) exports every msh_* function include/ministark_host.h declares."""
+    from mini_stark_amd.host import build_host_library
+    text = open(os.path.join(ROOT, "include", "ministark_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(msh_[a-z0-9_]+)\s*\(", text)))
+    assert len(syms) >= 15
+    ctypes.CDLL(ms.build_library(), mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(build_host_library())
+    assert not [s_ for s_ in syms if not hasattr(lib, s_)]

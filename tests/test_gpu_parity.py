@@ -332,3 +332,37 @@ def test_config4_wide_air_2p22_rows_bit_exact_vs_oracle(mk):
     finally:
         orc.set_threads(1)
     print(f"configs[4] wide AIR 2^22 rows: bit-exact vs oracle in {time.time() - t0:.0f} s ({_oracle_threads()} oracle threads)")
+
+
+def test_rccl_binding_selftest(mk):
+    """ms_set_shard_rccl's plumbing on one GPU: librccl.so bound at run time, a one-rank communicator, send/recv to self in a
+    group, all-gather and both all-reduces on the context's stream with checked payloads."""
+    ctx = mk(0, fresh=True)
+    assert len(ctx.rccl_unique_id()) == 128
+    rc = ctx.L.ms_rccl_selftest(ctx.h)
+    assert rc == 0, ctx.last_error()
+    ctx.set_shard_rccl(0, 1, bytes(128), 0)   # world 1 = sharding off
+    pc.case_prove(lambda f, fresh=False: ctx, 0, 8, 8, read_big=False)
+
+
+@pytest.mark.parametrize("field,log_n", [(0, 12), (1, 10), (0, 18)])
+def test_mssp_roundtrip_across_processes(mk, field, log_n, tmp_path):
+    """SURVEY 8(f) rank 3 on the HIP build: a GPU proof serialised by the C++ host mirror (msh_proof_serialize, MSSP), written to a
+    file, deserialised and verified in a FRESH process (tests/verify_worker.py: msh_stark_verify_mssp)."""
+    import subprocess
+    import sys
+    from mini_stark_amd.host import HostStark, build_host_library
+    from mini_stark_amd.stark import fibonacci_air, StarkProof
+    build_host_library()
+    ctx = mk(field)
+    steps = (1 << log_n) - 1
+    tt = fibonacci_air(ctx, steps)
+    hs = HostStark(ctx, 20, 8, steps, tt.constrain_number())
+    proof = hs.prove(tt)
+    wire = hs.proof_bytes()
+    assert wire == proof.to_bytes() and StarkProof.from_bytes(wire).fri_proof.blob == proof.fri_proof.blob
+    f = tmp_path / "proof.mssp"
+    f.write_bytes(wire)
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "verify_worker.py"), str(f), str(field), str(steps), "8"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "VERIFY accepted tampered-rejected" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])

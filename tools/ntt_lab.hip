@@ -7,29 +7,16 @@
 #include <vector>
 #include "../mini-stark_amd/csrc/ntt.hpp"
 
-// ---- variant 0: the r01 formulation (compare + select), kept here for A/B
+// ---- variant 0: the r01 formulation (compare + select) = field.hpp GL
 struct GL0 {
-  static constexpr u64 P = GL::P, EPS = GL::EPS;
-  static MS_HD u64 add(u64 a, u64 b) { const u64 s = a + b; const u64 t = s - P; return (s < a || s >= P) ? t : s; }
-  static MS_HD u64 sub(u64 a, u64 b) { u64 d = a - b; if (a < b) d -= EPS; return d; }
-  static MS_HD u64 reduce128(u64 lo, u64 hi) {
-    const u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
-    u64 t0 = lo - hi_hi; t0 -= (lo < hi_hi) ? EPS : 0;
-    const u64 t1 = (hi_lo << 32) - hi_lo;
-    const u64 r = t0 + t1; const u64 r2 = r + EPS;
-    return (r < t1 || r >= P) ? r2 : r;
-  }
-  template <int S> static MS_HD u64 mul_pow2(u64 x) {
-    if constexpr (S == 0) return x;
-    else if constexpr (S < 64) return reduce128(x << S, x >> (64 - S));
-    else { constexpr int A = S - 32, B = S - 64; const u64 alo = x << A, ahi = x >> (64 - A); const u64 blo = x << B, bhi = (B == 0) ? 0 : (x >> ((64 - B) & 63));
-      const u64 lo = alo - blo; const u64 hi = ahi - bhi - (alo < blo ? 1 : 0); return reduce128(lo, hi); }
-  }
+  static MS_HD u64 add(u64 a, u64 b) { return GL::add(a, b); }
+  static MS_HD u64 sub(u64 a, u64 b) { return GL::sub(a, b); }
+  template <int S> static MS_HD u64 mul_pow2(u64 x) { return msntt::gl_mul_pow2_v1<S>(x); }
 };
 // ---- variant 1: the r02 formulation (sign-bit decisions via v_bitop3)
 struct GL1 {
-  static MS_HD u64 add(u64 a, u64 b) { return GL::add(a, b); }
-  static MS_HD u64 sub(u64 a, u64 b) { return GL::sub(a, b); }
+  static MS_HD u64 add(u64 a, u64 b) { return GLT::add(a, b); }
+  static MS_HD u64 sub(u64 a, u64 b) { return GLT::sub(a, b); }
   template <int S> static MS_HD u64 mul_pow2(u64 x) { return msntt::gl_mul_pow2<S>(x); }
 };
 // ---- variant 2: LAZY (NOT exact: single-fix add/sub on [0, 2^64), for cost exploration only)
@@ -150,7 +137,7 @@ template <class A, int B, int MODE> __global__ void __launch_bounds__(256) lab(u
   for (int it = 0; it < iters; it++) {
     if (MODE == 0) Stage<A, B, B - 1, 0, 0>::run(x);                                      // full radix-2^B DIF (adds, subs, shift twiddles)
     if (MODE == 1) { for (int i = 0; i < (1 << B); i += 2) { u64 a = x[i], b = x[i + 1]; x[i] = A::add(a, b); x[i + 1] = A::sub(a, b); } }  // add/sub only
-    if (MODE == 2) { _Pragma("unroll") for (int i = 0; i < (1 << B); i++) x[i] = GL::mul(x[i], x[(i + 1) & ((1 << B) - 1)]); }               // general multiplies
+    if (MODE == 2) { _Pragma("unroll") for (int i = 0; i < (1 << B); i++) x[i] = GLT::mul(x[i], x[(i + 1) & ((1 << B) - 1)]); }              // general multiplies
     if constexpr (MODE == 3) { _Pragma("unroll") for (int i = 0; i < (1 << B); i++) x[i] = A::mul(x[i], x[(i + 1) & ((1 << B) - 1)]); }
   }
   u64 s = 0;
@@ -181,7 +168,7 @@ template <class A> __global__ void check_k(u64* out, const u64* in, int n) {
   o[3] = A::template mul_pow2<3>(a); o[4] = A::template mul_pow2<31>(a); o[5] = A::template mul_pow2<32>(a); o[6] = A::template mul_pow2<45>(a);
   o[7] = A::template mul_pow2<63>(a); o[8] = A::template mul_pow2<64>(a); o[9] = A::template mul_pow2<78>(a); o[10] = A::template mul_pow2<95>(a); o[11] = A::template mul_pow2<12>(b);
 }
-struct GLr { static MS_HD u64 add(u64 a, u64 b) { return GL::add(a, b); } static MS_HD u64 sub(u64 a, u64 b) { return GL::sub(a, b); } static MS_HD u64 mul(u64 a, u64 b) { return GL::mul(a, b); }
+struct GLr { static MS_HD u64 add(u64 a, u64 b) { return GLT::add(a, b); } static MS_HD u64 sub(u64 a, u64 b) { return GLT::sub(a, b); } static MS_HD u64 mul(u64 a, u64 b) { return GLT::mul(a, b); }
   template <int S> static MS_HD u64 mul_pow2(u64 x) { return msntt::gl_mul_pow2<S>(x); } };
 static u64 href_mulmod(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % GL::P); }
 template <class A> int check(const char* name) {
@@ -210,7 +197,7 @@ template <class A> int check(const char* name) {
   return bad;
 }
 int main() {
-  check<GLr>("r02 bit-trick (field.hpp)");
+  check<GLr>("r02 sign-bit GLT (field.hpp)");
   check<GL3>("masked asm");
 
   u64 *d_in, *d_out;
