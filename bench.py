@@ -8,31 +8,154 @@ A "step" is one complete proof of the hot path (src/starks.rs:59-169 between
 "trace filled" and "StarkProof returned"): trace commit, INTT, coset LDE,
 LDE commit, mix, DEEP-ALI evaluations, FRI commit phase (all rounds) and FRI
 query phase, with the Fibonacci-AIR trace already resident in HBM and the FRI
-proof left resident in HBM (PCIe-inclusive rate: see DESIGN.md).  Workload at
-every N: BASELINE.json configs[1] — Fibonacci AIR, Goldilocks, 2^20 trace rows,
-blowup 8, 20 security bits — one independent proof per step per rank (weak
-scaling: the path partitions over proofs; no data-path collective).
-`--mode shard` instead computes ONE proof per step with all ranks together
-(ms_set_shard: RCCL digest all-to-all + root all-gather per large commitment;
-strong scaling) — the latency configuration for single large proofs
-(`--log-rows 24` = BASELINE.json configs[3]).
+proof left resident in HBM (the PCIe-inclusive rate is the `value_with_io`
+leg).  Headline workload at every N: BASELINE.json configs[1] — Fibonacci AIR,
+Goldilocks, 2^20 trace rows, blowup 8, 20 security bits — independent proofs on
+every rank (weak scaling: the path partitions over proofs; no data-path
+collective).
 
-Rank 0 prints ONE JSON line.  Extra legs (rank 0, outside the timed region):
-  roofline     — per-kernel HIP-event timings on the launching stream for the
-                 NTT pass kernel vs its algorithmic bytes
-  cpu_baseline — the CPU oracle ("port") on a bounded sample, N == 1 only.
+Rank 0 prints ONE JSON line.  Besides the headline it carries
+  roofline       per-kernel HIP-event timing of the dominant NTT pass kernel vs its algorithmic bytes
+  roofline_valu  the SHA-256 kernels (59 % of the kernel time) against the VALU issue roofline
+  sharded        N > 1 only: ONE 2^24-row proof (BASELINE configs[3]) computed by all ranks together (ms_set_shard_rccl:
+                 coset-partitioned LDE/FRI + leaf hashing, RCCL digest all-to-all + root all-gather inside the library;
+                 strong scaling), under a watchdog so that a failure there cannot take the headline down
+  extra          N == 1 only: 2^24-row Goldilocks and 2^20-row BabyBear+Fp4 proofs/s, NTT-only GB/s at 2^20 and 2^24 rows,
+                 and `value_with_io` (trace from pinned host memory, FRI proof read back, overlapped over the in-flight lanes)
+  cpu_baseline   N == 1 only: the CPU oracle ("port") on the same 2^20-row proof, 1 thread and OpenMP
+`--mode shard` makes the sharded proof the timed step instead (the latency configuration for single large proofs).
 """
 import argparse
 import ctypes as C
+import csv
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32, 2.4 GHz max clock (same guide)
+
+
+def default_inflight(log_rows):
+    # 8 fills the 4 hardware queues twice over at the benchmark size; larger proofs need the HBM (25 GiB each at 2^24 rows)
+    return 8 if log_rows <= 20 else (4 if log_rows == 21 else (3 if log_rows == 22 else 2))
+
+
+class Lanes:
+    """`inflight` independent provers on one GPU: one ms_ctx (own HIP stream, own HBM buffers), one host thread and one C++
+    host-mirror Stark each.  io=False: traces resident in HBM, FRI proofs left in HBM.  io=True: every proof uploads its trace
+    from page-locked host memory and reads the FRI proof back into page-locked host memory."""
+
+    def __init__(self, field, log_rows, blowup, inflight, device_index, dev, seed0=2, io=False):
+        import numpy as np
+        import torch
+        import mini_stark_amd as ms
+        from mini_stark_amd.stark import StarkConfig, fibonacci_air
+        from mini_stark_amd.host import HostStark
+        self.ms, self.io, self.n = ms, io, inflight
+        steps = (1 << log_rows) - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
+        self.ctxs = [ms.Context(field, device=device_index) for _ in range(inflight)]
+        self.tts = [fibonacci_air(c, steps, secret_b=seed0 + i) for i, c in enumerate(self.ctxs)]
+        self.cfg = StarkConfig(self.ctxs[0], 20, blowup, steps, self.tts[0].constrain_number())
+        self.starks = [HostStark(c, 20, blowup, steps, self.tts[0].constrain_number()) for c in self.ctxs]
+        if io:
+            self.pinned = [torch.from_numpy(t.data.view(np.int64)).pin_memory() for t in self.tts]
+            for t, pt in zip(self.tts, self.pinned):   # prove_raw takes the host pointer from trace.data
+                t.data = pt.numpy().view(np.uint64)
+            self.d_traces = [None] * inflight
+        else:
+            self.d_traces = [torch.from_numpy(t.data.view(np.int64)).to(dev) for t in self.tts]  # resident in HBM before the timed region
+        torch.cuda.synchronize()
+        self.last = [None] * inflight
+
+    def _prove_n(self, i, n):
+        ptr = None if self.io else self.d_traces[i].data_ptr()
+        for _ in range(n):
+            self.ctxs[i].check(self.starks[i].prove_raw(self.tts[i], trace_device_ptr=ptr, read_fri_proof=self.io))
+        self.last[i] = self.starks[i].last_proof(read_fri_proof=False)
+
+    def run(self, n):  # n steps = n proofs on each lane (ctypes releases the GIL inside the library)
+        if self.n == 1:
+            self._prove_n(0, n)
+            return
+        th = [threading.Thread(target=self._prove_n, args=(i, n)) for i in range(self.n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    def timed(self, grp, steps, warmup):
+        self.run(warmup)
+        grp.barrier()
+        t0 = time.perf_counter()
+        self.run(steps)
+        grp.barrier()
+        return grp.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        self.starks = None
+        for c in self.ctxs:
+            c.close()
+        self.d_traces = None
+
+
+def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
+    """ONE proof per step computed by all ranks together; the collectives run inside the library (RCCL) unless --backend gloo."""
+    import torch
+    import mini_stark_amd as ms
+    from mini_stark_amd.stark import StarkConfig, fibonacci_air
+    from mini_stark_amd.host import HostStark
+    from mini_stark_amd.dist import RcclShard, ShardExchange
+    N = 1 << log_rows
+    ctx = ms.Context(args.field, device=local_rank)
+    cap = 32 * N * args.blowup // grp.world + (4 << 20)   # leaf digests of the largest commitment / world + the query phase's Merkle paths
+    if args.backend == "nccl":
+        xchg = RcclShard(grp, ctx, cap)
+        how = "RCCL inside the library (ms_set_shard_rccl): ncclSend/ncclRecv all-to-all of leaf digests + ncclAllGather of subtree roots per large commitment, 2 ncclAllReduce in the query phase, all on the prover's stream"
+    else:
+        dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
+        xchg = ShardExchange(grp, ctx, cap, staged=True, buffer_device=dev)
+        how = "gloo rehearsal through the exchange callback (payloads staged through host memory)"
+    tt = fibonacci_air(ctx, N - 1)   # every rank holds the same trace
+    cfg = StarkConfig(ctx, 20, args.blowup, N - 1, tt.constrain_number())
+    hs = HostStark(ctx, 20, args.blowup, N - 1, tt.constrain_number())
+    d_trace = torch.from_numpy(tt.data.view("int64")).to(torch.device("cuda", local_rank % max(1, torch.cuda.device_count())))
+    torch.cuda.synchronize()
+
+    def prove(n):
+        for _ in range(n):
+            ctx.check(hs.prove_raw(tt, trace_device_ptr=d_trace.data_ptr(), read_fri_proof=False))
+    prove(warmup)
+    grp.barrier()
+    t0 = time.perf_counter()
+    prove(steps)
+    grp.barrier()
+    el = grp.max_over_ranks(time.perf_counter() - t0)
+    roots = grp.all_gather_bytes(hs.last_proof(read_fri_proof=False).fri_roots[-1])
+    calls = xchg.calls
+    res = {"workload": f"Fibonacci AIR, {'Goldilocks' if args.field == 0 else 'BabyBear+Fp4'}, 2^{log_rows} trace rows, blowup {args.blowup} (rounds={cfg.rounds}): ONE proof per step over {grp.world} ranks",
+           "scaling": "strong", "value": steps / el, "unit": "proofs/s", "ms_per_proof": el / steps * 1e3, "steps": steps, "warmup": warmup,
+           "ranks_in_communicator": grp.world, "parallelism": how, "all_ranks_same_final_root": len(set(roots)) == 1,
+           "collective_calls_per_rank": {n: calls[i] for i, n in enumerate(["all_to_all", "all_gather", "all_reduce_min", "all_reduce_sum"])},
+           "bytes_sent_per_rank": xchg.bytes, "proofs": steps + warmup}
+    xchg.close()
+    ctx.close()
+    return res, cfg
+
+
+def load_sq_profile():
+    """VALU wave-instructions per thread per (kernel, grid) from this round's rocprofv3 SQ-counter pass (tools/process_profiles.py)."""
+    for name in ("r02_sq_counters_top_kernels.csv", "r01_sq_counters_top_kernels.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            rows = list(csv.DictReader(open(path)))
+            return name, rows
+    return None, []
 
 
 def main():
@@ -44,11 +167,16 @@ def main():
     ap.add_argument("--blowup", type=int, default=8)
     ap.add_argument("--field", type=int, default=0, help="0 Goldilocks, 1 BabyBear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-rows", type=int, default=18)
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (2^24 rows, BabyBear, NTT-only, I/O-inclusive) of the N = 1 run")
+    ap.add_argument("--cpu-log-rows", type=int, default=20, help="size of the CPU baseline's sample proof (default: the benchmark size itself, no extrapolation)")
     ap.add_argument("--inflight", type=int, default=None, help="independent proofs in flight per GPU (one ms_ctx + HIP stream each); a step = this many proofs (default: 8 up to 2^20 rows, fewer above)")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
-                    help="replicas (default): every rank proves its own traces, no data-path collective (weak scaling).  shard: ONE proof per step computed by all "
-                         "ranks together (ms_set_shard: coset-partitioned LDE/FRI + leaf hashing, RCCL digest all-to-all and root all-gather; strong scaling)")
+                    help="replicas (default): every rank proves its own traces, no data-path collective (weak scaling); with N > 1 ranks a sharded 2^24-row proof is "
+                         "measured as a second leg.  shard: ONE proof per step computed by all ranks together is the timed step (strong scaling)")
+    ap.add_argument("--shard-log-rows", type=int, default=24, help="size of the sharded leg's proof (BASELINE configs[3]: 24)")
+    ap.add_argument("--shard-steps", type=int, default=3)
+    ap.add_argument("--no-shard-leg", action="store_true")
+    ap.add_argument("--shard-timeout", type=float, default=420.0, help="watchdog for the sharded leg (seconds)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL, one GPU per rank (the measured configuration).  gloo: rehearsal of the N>1 paths on a box with fewer GPUs than ranks "
                          "(ranks share GPUs, exchange payloads are staged through host memory)")
@@ -57,91 +185,73 @@ def main():
     import numpy as np
     import torch
     import mini_stark_amd as ms
-    from mini_stark_amd.stark import StarkConfig, fibonacci_air
-    from mini_stark_amd.host import HostStark  # C++ mirror of StarkConfig::new / Stark::prove above the C ABI
-
     from mini_stark_amd.dist import Group
     grp = Group(args.backend)
     world, rank, local_rank, dev = grp.world, grp.rank, grp.local_rank, grp.device
     if args.backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())
         dev = torch.device("cuda", local_rank)
+    if args.inflight is None:
+        args.inflight = default_inflight(args.log_rows)
+    field_name = "Goldilocks" if args.field == 0 else "BabyBear+Fp4"
+    out = None
 
-    N = 1 << args.log_rows
-    steps = N - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
-    import threading
-    if args.inflight is None:  # 8 fills the 4 hardware queues twice over at the benchmark size; larger proofs need the HBM (25 GiB each at 2^24 rows)
-        args.inflight = 8 if args.log_rows <= 20 else (4 if args.log_rows == 21 else (3 if args.log_rows == 22 else 2))
-    shard = args.mode == "shard" and world > 1
-    C_IN = 1 if shard else max(1, args.inflight)
-    # one context (own HIP stream, own HBM buffers) per in-flight proof; raises if libministark.so / the GPU is missing
-    ctxs = [ms.Context(args.field, device=local_rank) for _ in range(C_IN)]
-    ctx = ctxs[0]
-    tts = [fibonacci_air(c, steps, secret_b=2 + (0 if shard else rank * C_IN) + i) for i, c in enumerate(ctxs)]  # shard: every rank holds the same trace
-    cfg = StarkConfig(ctx, 20, args.blowup, steps, tts[0].constrain_number())
-    starks = [HostStark(c, 20, args.blowup, steps, tts[0].constrain_number()) for c in ctxs]
-    d_traces = [torch.from_numpy(t.data.view(np.int64)).to(dev) for t in tts]  # resident in HBM before the timed region
-    torch.cuda.synchronize()
-    last = [None] * C_IN
-    xchg = None
-    if shard:  # exchange buffers: the leaf digests of the largest commitment (32 B x L / world) + the query phase's Merkle paths
-        from mini_stark_amd.dist import ShardExchange
-        xchg = ShardExchange(grp, ctx, 32 * N * args.blowup // world + (4 << 20), staged=args.backend == "gloo", buffer_device=dev)
+    if args.mode == "shard" and world > 1:
+        res, cfg = sharded_leg(args, grp, local_rank, args.log_rows, args.steps, args.warmup)
+        out = {"metric": "stark_proofs_per_s", "value": res["value"], "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": res["ms_per_proof"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64" if args.field == 0 else "u32",
+               "data": "synthetic", "config": {"workload": res["workload"], "proofs_per_step_per_gpu": 1.0 / world, "parallelism": res["parallelism"]}, "exchange": res}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        grp.close()
+        return
 
-    def prove_n(i, n):
-        for _ in range(n):
-            ctxs[i].check(starks[i].prove_raw(tts[i], trace_device_ptr=d_traces[i].data_ptr(), read_fri_proof=False))
-        last[i] = starks[i].last_proof(read_fri_proof=False)
-
-    def run_steps(n):  # n steps = n proofs on each of the C_IN in-flight lanes (ctypes releases the GIL inside the library)
-        if C_IN == 1:
-            prove_n(0, n)
-            return
-        th = [threading.Thread(target=prove_n, args=(i, n)) for i in range(C_IN)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-
-    def step():
-        prove_n(0, 1)
-        return last[0]
-
-    run_steps(args.warmup)
-    grp.barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    grp.barrier()
-    elapsed = grp.max_over_ranks(time.perf_counter() - t0)
-    proof = last[0]
-    # every rank's final FRI root, gathered over RCCL (outside the timed region): all ranks finished a proof
-    final_roots = grp.all_gather_bytes(proof.fri_roots[-1])
+    # ---- headline leg: independent proofs on every rank
+    lanes = Lanes(args.field, args.log_rows, args.blowup, max(1, args.inflight), local_rank, dev, seed0=2 + rank * max(1, args.inflight))
+    cfg, C_IN = lanes.cfg, lanes.n
+    elapsed = lanes.timed(grp, args.steps, args.warmup)
+    final_roots = grp.all_gather_bytes(lanes.last[0].fri_roots[-1])  # every rank finished a proof (outside the timed region)
     assert len(final_roots) == world
-    ms_per_step = elapsed / args.steps * 1e3
-    value = (1 if shard else world) * args.steps * C_IN / elapsed
-
     out = {
-        "metric": "stark_proofs_per_s", "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+        "metric": "stark_proofs_per_s", "value": world * args.steps * C_IN / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64" if args.field == 0 else "u32", "data": "synthetic",
-        "config": {"workload": f"Fibonacci AIR, {'Goldilocks' if args.field == 0 else 'BabyBear+Fp4'}, 2^{args.log_rows} trace rows, blowup {args.blowup}, 20 security bits "
+        "config": {"workload": f"Fibonacci AIR, {field_name}, 2^{args.log_rows} trace rows, blowup {args.blowup}, 20 security bits "
                                f"(w=3, c=6, rounds={cfg.rounds}, ood_queries={cfg.constrain_queries}, fri_queries={cfg.fri_queries}); a step = {C_IN} independent proofs in flight per GPU",
                    "proofs_per_step_per_gpu": C_IN, "parallelism": f"replicas x{world} GPUs x {C_IN} in-flight proofs (no data-path collective)"},
     }
-    if shard:
-        out["config"]["parallelism"] = f"one proof sharded over {world} GPUs (ms_set_shard): digest all-to-all + root all-gather per large commitment over RCCL"
-        out["config"]["workload"] = out["config"]["workload"].split("; a step")[0] + f"; a step = 1 proof computed by {world} ranks together"
-        out["config"]["proofs_per_step_per_gpu"] = 1.0 / world
-        out["exchange"] = {"collective_calls_per_rank": {n: xchg.calls[i] for i, n in enumerate(["all_to_all", "all_gather", "all_reduce_min", "all_reduce_sum"])},
-                           "bytes_through_callback_per_rank": xchg.bytes, "proofs": args.steps + args.warmup}
 
-    if shard and rank != 0:
-        step()  # the roofline leg's extra proof is collective in shard mode
+    # ---- N > 1: the sharded proof of BASELINE configs[3] as a second leg, behind a watchdog
+    if world > 1 and not args.no_shard_leg:
+        lanes.close()
+        lanes = None
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(args.shard_timeout):
+                if rank == 0:
+                    out["sharded"] = {"error": f"the sharded leg did not finish within {args.shard_timeout:.0f} s; headline unaffected"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            res, _ = sharded_leg(args, grp, local_rank, args.shard_log_rows, args.shard_steps, 1)
+            out["sharded"] = res
+        except Exception as e:  # noqa: BLE001 - reported in the JSON line; the other ranks are released by their watchdogs
+            out["sharded"] = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        done.set()
+
     if rank == 0:
+        if lanes is None:
+            lanes = Lanes(args.field, args.log_rows, args.blowup, 1, local_rank, dev)
+        ctx = lanes.ctxs[0]
         # ---- roofline leg: per-kernel HIP events on the launching stream, one extra (untimed) proof
         buf = C.create_string_buffer(1 << 14)
         ctx.check(ctx.L.ms_profile_begin(ctx.h))
-        step()
+        lanes._prove_n(0, 1)
         ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
         prof = json.loads(buf.value.decode())
         variants = prof.pop("ntt_pass_variants")
@@ -149,29 +259,120 @@ def main():
         kname, k = max(variants.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = k["ms"] / max(1, k["launches"])
         achieved = (k["alg_bytes"] / max(1, k["launches"])) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_ntt_pass.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                if pj.get("kernel") == kname:
-                    traffic = pj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = None, None
+        for name in ("r02_pmc_ntt_pass.json", "pmc_ntt_pass.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                try:
+                    pj = json.load(open(pmc))
+                    if pj.get("kernel") == kname:
+                        traffic, traffic_src = pj.get("hbm_bytes_per_launch"), "profiles/" + name
+                        break
+                except Exception:
+                    pass
         allp = prof["ntt_pass"]
         out["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic, "launches_per_proof": k["launches"], "avg_launch_ms": avg_ms, "alg_bytes_per_launch": k["alg_bytes"] / max(1, k["launches"]),
+                           "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round, gfx950 corrections applied; a constant, not measured in this run)") if traffic_src else None,
+                           "frac_on_traffic": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
+                           "launches_per_proof": k["launches"], "avg_launch_ms": avg_ms, "alg_bytes_per_launch": k["alg_bytes"] / max(1, k["launches"]),
                            "all_ntt_pass_kernels": {"launches_per_proof": allp["launches"], "ms_per_proof": allp["ms"],
                                                     "alg_GBps": allp["alg_bytes"] / (allp["ms"] * 1e-3) / 1e9 if allp["ms"] else 0.0},
-                           "note": "pass kernels are integer-VALU-issue bound on MI355X (DESIGN.md 6.2): ~4.4 cycles per wave-instruction, 36.7 T int-op/s"}
+                           "note": "pass kernels are bound by the NUMBER of VALU instructions (3.3-3.6 issue cycles each in integer code, tools/ntt_lab.hip), not by HBM (DESIGN.md 6.2)"}
         tot = sum(v["ms"] for v in prof.values()) or 1.0
         out["kernel_ms_per_proof"] = {n: round(v["ms"], 4) for n, v in prof.items() if v["launches"]}
         out["kernel_ms_total_single_proof"] = tot
         sha = prof["leaf_hash"]["ms"] + prof["inner_hash"]["ms"]
         out["sha256_share_of_kernel_time"] = sha / tot
 
-        # ---- CPU baseline leg (N == 1): oracle "port", single thread, bounded sample
+        # ---- VALU roofline of the SHA-256 kernels: wave-instructions issued per second against the issue peak
+        sq_name, sq = load_sq_profile()
+        if sq and args.log_rows == 20 and args.field == 0:
+            def wave_instr(prefixes):   # per proof: sum over the profiled (kernel, grid) pairs of the class
+                t = 0.0
+                for r in sq:
+                    if any(r["kernel"].startswith(p) for p in prefixes):
+                        t += float(r["dispatches"]) / float(r.get("proofs_profiled", 2) or 2) * float(r["grid_threads"]) / 64.0 * float(r["valu_wave_instr_per_thread"])
+                return t
+            peak_guide = N_SIMD * CLOCK_HZ / 2.0      # SIMD-32: a wave64 VALU instruction occupies the SIMD for 2 cycles
+            peak_meas = N_SIMD * CLOCK_HZ / 3.4       # measured: 3.3-3.6 cycles per VALU instruction in register-resident integer code (tools/ntt_lab.hip, r02)
+            rv = {}
+            for cls, prefixes in (("leaf_hash", ("msmerkle::LeafHashKernel", "msmerkle::PadOnlyBlockKernel")), ("inner_hash", ("msmerkle::InnerHashKernelT",))):
+                wi = wave_instr(prefixes)
+                ms_cls = prof[cls]["ms"]
+                if wi and ms_cls:
+                    rate = wi / (ms_cls * 1e-3)
+                    rv[cls] = {"valu_wave_instr_per_proof": wi, "ms_per_proof": ms_cls, "achieved_wave_instr_per_s": rate,
+                               "frac_of_guide_peak": rate / peak_guide, "frac_of_measured_issue_peak": rate / peak_meas}
+            out["roofline_valu"] = {"bound": "valu_issue", "unit": "wave-instr/s", "peak_guide": peak_guide, "peak_guide_basis": "MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op = 2 cycles, 2.4 GHz",
+                                    "peak_measured": peak_meas, "peak_measured_basis": "3.4 cycles per VALU instruction: what register-resident integer butterfly code sustains at >= 4 waves/SIMD whatever the opcode mix "
+                                    "(tools/ntt_lab.hip, profiles/r02_ntt_lab.log); the per-opcode costs of tools/valu_rate.hip did not carry over to mixed code",
+                                    "instr_source": "profiles/" + sq_name + " (rocprofv3 --pmc SQ_INSTS_VALU per dispatch; constants, not measured in this run)",
+                                    "times": "live: HIP events of this run, one proof alone (small tree levels are latency-bound, which lowers the class average)", "kernels": rv}
+
+        if world == 1 and not args.no_extras and args.log_rows == 20 and args.field == 0:
+            lanes.close()
+            lanes = None
+            extra = {}
+
+            def leg(name, fn):
+                try:
+                    extra[name] = fn()
+                except Exception as e:  # noqa: BLE001 - an extra leg must not take the headline down
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"}
+
+            def proofs_leg(field, log_rows, steps, warmup, inflight=None, io=False):
+                infl = inflight or default_inflight(log_rows)
+                ln = Lanes(field, log_rows, args.blowup, infl, local_rank, dev, io=io)
+                el = ln.timed(grp, steps, warmup)
+                lat = None
+                if not io:
+                    t0 = time.perf_counter(); ln._prove_n(0, 2); lat = (time.perf_counter() - t0) / 2 * 1e3
+                r = {"value": steps * infl / el, "unit": "proofs/s", "ms_per_proof_in_flight": el / (steps * infl) * 1e3, "in_flight": infl, "steps": steps, "rounds": ln.cfg.rounds}
+                if lat is not None:
+                    r["ms_single_proof_latency"] = lat
+                ln.close()
+                return r
+            leg("goldilocks_2p24_rows", lambda: dict(proofs_leg(0, 24, 4, 1), workload="BASELINE configs[3] per GPU: Fibonacci AIR, Goldilocks, 2^24 rows, blowup 8 (L = 2^27, ~25 GiB resident per proof)"))
+            leg("babybear_fp4_2p20_rows", lambda: dict(proofs_leg(1, 20, 10, 2), workload="BASELINE configs[2]: Fibonacci AIR, BabyBear + quartic extension, 2^20 rows, blowup 8 (u32 storage)"))
+            leg("value_with_io", lambda: dict(proofs_leg(0, 20, 10, 2, io=True), workload="configs[1] with the boundary's I/O inside the timed region: every proof uploads its 24 MiB trace from page-locked "
+                                              "host memory and reads its ~64 MiB FRI proof back into page-locked host memory (PCIe Gen5 x16), overlapped across the in-flight lanes"))
+
+            def ntt_only():
+                res = {}
+                os.environ["MS_LDE_LINEAR"] = "0"   # six transforms (no linear-provenance shortcut): the kernel measurement
+                try:
+                    from mini_stark_amd.stark import fibonacci_air
+                    stream = torch.cuda.Stream(device=dev)
+                    for lr, reps in ((20, 20), (24, 3)):
+                        c2 = ms.Context(0, device=local_rank)
+                        c2.set_stream(stream.cuda_stream)
+                        tt = fibonacci_air(c2, (1 << lr) - 1)
+                        with torch.cuda.stream(stream):
+                            c2.check(c2.trace_commit(tt.data, 6)[0]); c2.check(c2.interpolate())
+                            for sc, idx in tt.transitions:
+                                c2.check(c2.polys_lincomb(sc, idx))
+                            c2.check(c2.bench_lde(args.blowup, 12345))
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(stream)
+                            for _ in range(reps):
+                                c2.check(c2.bench_lde(args.blowup, 12345))
+                            e1.record(stream)
+                        torch.cuda.synchronize()
+                        ms_per = e0.elapsed_time(e1) / reps
+                        alg = 6 * ((1 << lr) + (1 << lr) * args.blowup) * 8
+                        res[f"coset_lde_6x2^{lr}_to_2^{lr + 3}"] = {"ms": ms_per, "alg_GBps": alg / ms_per / 1e6, "frac_of_hbm_peak": alg / ms_per / 1e6 / HBM_PEAK_GBS,
+                                                                    "alg_bytes": alg, "what": "scale + NTT passes of six columns, device resident, HIP events on the launching stream"}
+                        c2.close()
+                finally:
+                    del os.environ["MS_LDE_LINEAR"]
+                return res
+            leg("ntt_only", ntt_only)
+            out["extra"] = extra
+
+        # ---- CPU baseline leg (N == 1): oracle "port" on the benchmark proof itself, single thread + OpenMP
         if world == 1 and not args.no_cpu_baseline:
+            if lanes is not None:
+                lanes.close()
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import parity_cases as pc
             from common import fibonacci_trace_fast
@@ -187,13 +388,11 @@ def main():
             except Exception:
                 cpu_model = "unknown"
             out["cpu_baseline"] = {"value": 1.0 / (ct * scale), "unit": "proofs/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
-                                   "sample": f"one 2^{cl}-row proof of the same AIR on the oracle (oracle/ministark_oracle.cpp, 1 thread) took {ct:.2f} s; "
-                                             f"scaled linearly x{int(scale)} to 2^{args.log_rows} rows (optimistic for the CPU: ignores the log factor)"}
-            # the same sample with OpenMP over the oracle's independent loops (columns, leaf groups, tree levels):
-            # what a rayon-enabled reference could reach on this host; the reference itself is single-threaded (README.md:33)
+                                   "sample": f"one 2^{cl}-row proof of the same AIR on the oracle (oracle/ministark_oracle.cpp, 1 thread, Goldilocks multiply = one 64x64 product + special-form reduction, "
+                                             f"at least as fast as arkworks' one-limb Montgomery) took {ct:.2f} s" + (f"; scaled linearly x{int(scale)}" if scale != 1 else " (the benchmark size itself: no extrapolation)")}
             ncpu = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0))))
             best = None
-            for nthr in sorted({t for t in (16, 32, 64, ncpu) if 1 < t <= ncpu}):  # the port's fork-join loops stop scaling well before 128 threads: keep the best
+            for nthr in sorted({t for t in (32, 64, ncpu) if 1 < t <= ncpu}):  # the port's fork-join loops stop scaling well before 128 threads: keep the best
                 orc.set_threads(nthr)
                 c0 = time.perf_counter()
                 pc.drive(orc.Session(args.field), args.field, tr, args.blowup, max(0, cfg.fri_queries - 2), seed=1, q_ood=cfg.constrain_queries, read_big=False)
@@ -203,7 +402,7 @@ def main():
             orc.set_threads(1)
             if best is not None:
                 out["cpu_baseline"]["all_cores"] = {"value": 1.0 / (best[0] * scale), "unit": "proofs/s", "cores": best[1], "kind": "port", "host_cpus": ncpu,
-                                                    "sample": f"same 2^{cl}-row proof with OpenMP x{best[1]} (best of 16/32/64/{ncpu} threads) took {best[0]:.2f} s"}
+                                                    "sample": f"same 2^{cl}-row proof with OpenMP x{best[1]} over the port's independent loops (best of the thread counts tried) took {best[0]:.2f} s"}
         print(json.dumps(out), flush=True)
     grp.close()
 

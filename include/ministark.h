@@ -62,6 +62,10 @@ const char* ms_last_error(const ms_ctx* ctx);
 int ms_ext_degree(const ms_ctx* ctx);             /* 2 (Goldilocks) / 4 (BabyBear): StarkField::Extension */
 int ms_set_stream(ms_ctx* ctx, void* hip_stream); /* run on a caller-owned hipStream_t (NULL: back to the ctx's own) */
 int ms_synchronize(ms_ctx* ctx);
+/* page-locked host memory for the boundary's bulk transfers (the trace going in, the FRI proof coming out): copies to and from
+ * it are DMA transfers that overlap with kernels of other contexts.  NULL on failure. */
+void* ms_pinned_alloc(size_t bytes);
+void ms_pinned_free(void* p);
 
 /* ---- one proof sharded over the GPUs of a node (no reference counterpart) ----
  * One process per GPU, every rank calls the SAME stage functions with the SAME inputs and gets the same

@@ -1482,6 +1482,8 @@ int ms_set_shard(ms_ctx* ctx, int rank, int world, void* d_send, void* d_recv, s
   B(ctx)->bind_device();
   return B(ctx)->set_shard(rank, world, d_send, d_recv, cap, fn, user);
 }
+void* ms_pinned_alloc(size_t bytes) { void* p = nullptr; return msrt::malloc_host(&p, bytes) ? nullptr : p; }
+void ms_pinned_free(void* p) { if (p) msrt::free_host(p); }
 int ms_rccl_unique_id(uint8_t out[128]) {
   if (!out) return MS_ERR_ARG;
   msrt::Rccl& R = msrt::Rccl::get();

@@ -96,11 +96,26 @@ struct TraceTable {
   size_t constrain_number() const { return width + transitions.size(); }  // air.rs:123-125
 };
 
+// byte buffer in page-locked host memory (ms_pinned_alloc: hipHostMalloc): the device copies the ~64 MiB FRI proof into it by DMA
+struct PinnedBuf {
+  u8* p = nullptr; size_t n = 0, cap = 0;
+  PinnedBuf() {}
+  PinnedBuf(const PinnedBuf& o) { assign(o.p, o.p + o.n); }
+  PinnedBuf& operator=(const PinnedBuf& o) { if (this != &o) assign(o.p, o.p + o.n); return *this; }
+  ~PinnedBuf() { if (p) ms_pinned_free(p); }
+  void reserve(size_t m) { if (m <= cap) return; if (p) ms_pinned_free(p); p = (u8*)ms_pinned_alloc(m); cap = p ? m : 0; }
+  void assign(size_t m, u8 v) { reserve(m); n = p ? m : 0; if (n) memset(p, v, n); }
+  void resize_uninit(size_t m) { reserve(m); n = p ? m : 0; }
+  void assign(const u8* a, const u8* b) { const size_t m = (size_t)(b - a); reserve(m); n = p ? m : 0; if (n) memcpy(p, a, n); }
+  u8* data() { return p; } const u8* data() const { return p; }
+  size_t size() const { return n; } bool empty() const { return n == 0; }
+};
+
 struct StarkProof {  // src/starks.rs:21-28 (+ the per-round roots and drawn challenges, for inspection)
   std::vector<u8> arthur; u8 trace_commit[32], constrain_trace_commit[32];
   std::vector<u64> evals;        // [q][c+1][E]: constrain_queries then validity_query per point
   std::vector<u8> fri_roots;     // rounds * 32 (round 0 first; round 0 is not in the transcript, as in the reference)
-  std::vector<u8> fri_blob;      // FriProof, MSFP layout (empty if left resident in HBM)
+  PinnedBuf fri_blob;            // FriProof, MSFP layout (empty if left resident in HBM); page-locked: read back by DMA
   std::vector<u64> challenges;   // shift, r, z[q*E], then per round z[E], alpha[E], finally betas
   size_t c = 0;
 };
@@ -129,7 +144,8 @@ struct Stark {
   // src/starks.rs:59-169
   int prove(const TraceTable& trace, bool read_fri_proof) {
     const StarkConfig& c = cfg; ms_ctx* ctx = c.ctx; const int e = c.e; const u64 p = c.p;
-    StarkProof& pr = proof; pr = StarkProof();
+    StarkProof& pr = proof;
+    pr.arthur.clear(); pr.evals.clear(); pr.fri_roots.clear(); pr.challenges.clear(); pr.c = 0; pr.fri_blob.n = 0;   // the page-locked proof buffer is kept across proofs
     Transcript t(c.domsep);
     int rc;
     // 1.1 commit to the raw trace (starks.rs:68-73)
@@ -175,7 +191,7 @@ struct Stark {
     if ((rc = ms_fri_query(ctx, betas.data(), (int)betas.size()))) return rc;
     pr.challenges.insert(pr.challenges.end(), betas.begin(), betas.end());
     if (read_fri_proof) {
-      pr.fri_blob.assign(ms_fri_proof_size(ctx), 0);
+      pr.fri_blob.resize_uninit(ms_fri_proof_size(ctx));
       if (!pr.fri_blob.empty() && (rc = ms_fri_proof_read(ctx, pr.fri_blob.data()))) return rc;
     }
     pr.arthur = t.prover_bytes;                                                 // starks.rs:160
