@@ -131,6 +131,104 @@ struct GLT : GL {
   static MS_HD T mul_tw(T a, T w_tab) { return mul(a, w_tab); }
 };
 
+// Goldilocks, EXEC-MASKED formulation (inline asm, gfx950 only; every other build falls back to GL's formulas): the conditional
+// corrections of add / sub / fold / reduce run as ONE 64-bit add under an exec mask set from the compare's SGPR result instead of
+// compare + select pairs: 4 VALU instructions per add or sub (7 / 6 in GL / GLT), 19 per general multiplication (27), SALU does the
+// mask plumbing.  Measured (tools/ntt_lab.hip): 7.8 VALU instructions and 28 issue cycles per element-stage of a radix-32 butterfly
+// network against 11.7 / 38 (GLT) - provided the SIMD holds >= 4 waves; at 2 waves per SIMD the exec writes are not hidden and it
+// loses to GLT (42 vs 39).  The NTT tiles choose the class by their occupancy.
+// Hazards handled inside the blocks: a VALU read of an SGPR/VCC written by the VALU instruction before it needs 2 wait states on
+// gfx950 (s_nop 1, or an SALU copy in between); SALU reads of VALU-written SGPRs and VALU after an SALU exec write are interlocked.
+struct GLM : GL {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static __device__ __forceinline__ T add(T a, T b) {
+    u64 s, sv;
+    asm("v_lshl_add_u64 %0, %2, 0, %3\n\t"
+        "v_cmp_lt_u64 vcc, %0, %2\n\t"            // carry out of a + b
+        "v_cmp_lt_u64 %1, %4, %0\n\t"             // s > P - 1
+        "s_or_b64 vcc, vcc, %1\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %5\n\t"        // s - P == s + EPS (mod 2^64)
+        "s_mov_b64 exec, %1"
+        : "=&v"(s), "=&s"(sv) : "v"(a), "v"(b), "s"(P - 1), "s"(EPS) : "vcc", "scc");
+    return s;
+  }
+  static __device__ __forceinline__ T sub(T a, T b) {
+    u64 d = a - b, sv;
+    asm("v_cmp_lt_u64 vcc, %2, %3\n\t"            // borrow
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %4\n\t"        // + P
+        "s_mov_b64 exec, %1"
+        : "+v"(d), "=&s"(sv) : "v"(a), "v"(b), "s"(P) : "vcc", "scc");
+    return d;
+  }
+  // A + h * EPS, canonical, for any u64 A and h < 2^32 (the true sum is < 2^65 - 2^33: at most one wrap, and a wrapped sum + EPS < P)
+  static __device__ __forceinline__ T fold(u64 A, u32 h) {
+    u64 sv;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %0\n\t"   // carry out in vcc
+        "v_cmp_lt_u64 %1, %3, %0\n\t"
+        "s_or_b64 vcc, vcc, %1\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(A), "=&s"(sv) : "v"(h), "s"(P - 1), "s"(EPS) : "vcc", "scc");
+    return A;
+  }
+  static __device__ __forceinline__ T fold_small(u64 A, u32 h) { return fold(A, h); }
+  static __device__ __forceinline__ T mul_x32(T z) { return fold(z << 32, hi(z)); }      // z0 * 2^32 + z1 * EPS
+  static __device__ __forceinline__ T mul_x64(T z) {                                      // z0 * EPS - z1
+    const u64 U = (u64)lo(z) * 0xFFFFFFFFu, h1 = (u64)hi(z);
+    u64 r = U - h1, sv;
+    asm("v_cmp_lt_u64 vcc, %2, %3\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(r), "=&s"(sv) : "v"(U), "v"(h1), "s"(P) : "vcc", "scc");
+    return r;
+  }
+  static __device__ __forceinline__ T mul(T a, T b) {
+    u64 T0, M, T1, c;
+    asm("v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
+        "v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %2, vcc, %5, %7, 0\n\t"
+        "v_mad_u64_u32 %1, %3, %5, %6, %1"        // M = a0*b1 + a1*b0, its carry in an SGPR pair
+        : "=&v"(T0), "=&v"(M), "=&v"(T1), "=&s"(c) : "v"(lo(a)), "v"(hi(a)), "v"(lo(b)), "v"(hi(b)) : "vcc");
+    // 128-bit (lo, hi) = T0 + M * 2^32 + T1 * 2^64 + c * 2^96;  r = lo - hi_hi, then + hi_lo * EPS
+    u32 L1, H0, H1, R0, R1; u64 bm;
+    asm("v_addc_co_u32 %2, vcc, %9, 0, %11\n\t"   // H1 = hi(T1) + c   (no wrap: the product is < 2^128)
+        "v_add_co_u32 %0, vcc, %6, %7\n\t"        // L1 = hi(T0) + lo(M)
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %1, vcc, %10, %8, vcc\n\t" // H0 = lo(T1) + hi(M) + carry
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %2, vcc, %2, 0, vcc\n\t"   // H1 += carry
+        "s_nop 0\n\t"
+        "v_sub_co_u32 %3, vcc, %12, %2\n\t"       // r = lo - H1
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %4, vcc, 0, %0, vcc\n\t"
+        "s_mov_b64 %5, vcc"                       // borrow mask
+        : "=&v"(L1), "=&v"(H0), "=&v"(H1), "=&v"(R0), "=&v"(R1), "=&s"(bm)
+        : "v"(hi(T0)), "v"(lo(M)), "v"(hi(M)), "v"(hi(T1)), "v"(lo(T1)), "s"(c), "v"(lo(T0)) : "vcc");
+    u64 R = mk(R0, R1), sv;
+    asm("s_and_saveexec_b64 %1, %3\n\t"           // borrow: r += P  (== - EPS)
+        "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %2, -1, %0\n\t"   // + hi_lo * EPS, carry in vcc
+        "v_cmp_lt_u64 %1, %5, %0\n\t"
+        "s_or_b64 vcc, vcc, %1\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %6\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(R), "=&s"(sv) : "v"(H0), "s"(bm), "s"(P), "s"(P - 1), "s"(EPS) : "vcc", "scc");
+    return R;
+  }
+  static __device__ __forceinline__ T mul_tw(T a, T w_tab) { return mul(a, w_tab); }
+#else
+  static MS_HD T fold_small(u64 A, u32 h) { return GLT::fold_small(A, h); }
+  static MS_HD T mul_x32(T z) { return GLT::mul_x32(z); }
+  static MS_HD T mul_x64(T z) { return GLT::mul_x64(z); }
+#endif
+};
+
 struct BB {
   typedef u32 T;
   static constexpr int ID = 1;

@@ -218,6 +218,17 @@ template <class F> struct Ctx : CtxBase {
   std::vector<ProfRec> prof_recs;
   double next_bytes = 0;  // algorithmic bytes attributed to the next launch
   int next_sub = 0;       // NTT pass variant of the next launch: K | 16*(TH==512) | 32*generic | 64*inverse
+  template <class K> int run_coop(int kid, unsigned gx, int threads, size_t lds, const typename K::Params& p) {
+    if (gx == 0) return 0;
+    if (!prof_on) return msrt::launch_coop<K>(stream, gx, 1, threads, lds, p);
+    ProfRec r; r.kid = kid; r.sub = next_sub; r.bytes = next_bytes; next_bytes = 0; next_sub = 0;
+    if (msrt::event_create(&r.a) || msrt::event_create(&r.b)) return 1;
+    msrt::event_record(r.a, stream);
+    int e = msrt::launch_coop<K>(stream, gx, 1, threads, lds, p);
+    msrt::event_record(r.b, stream);
+    prof_recs.push_back(r);
+    return e;
+  }
   template <class K> int run(int kid, unsigned gx, unsigned gy, int threads, size_t lds, const typename K::Params& p) {
     if (gx == 0 || gy == 0) return 0;
     if (!prof_on) return msrt::launch<K>(stream, gx, gy, threads, lds, p);
@@ -255,7 +266,8 @@ template <class F> struct Ctx : CtxBase {
     for (auto& kv : sub_ms) {
       const int sub = kv.first; char name[160], buf[320];
       const char* fld = F::ID == 0 ? "GL" : "BB";
-      if (sub & 128) snprintf(name, sizeof name, "msntt::PassKernel2<%s, %s, %d, %d, 256>", fld, (sub & 64) ? "true" : "false", sub & 15, (sub >> 8) & 7);
+      if (sub & 128) snprintf(name, sizeof name, "msntt::PassKernel2<%s, %s, %s, %d, %d, %d, %d, %d>", fld, (sub & 2048) ? "GLM" : (F::ID == 0 ? "GLT" : "BB"), (sub & 64) ? "true" : "false",
+                              sub & 15, (sub >> 8) & 7, (sub & 2048) ? (((sub >> 8) & 7) == 4 ? 1024 : 512) : 256, (sub & 2048) ? 3 : 2, (sub >> 12) & 3);
       else if (sub & 32) snprintf(name, sizeof name, "msntt::PassKernel<%s, %s, %d>", fld, (sub & 64) ? "true" : "false", (sub & 16) ? 512 : 256);
       else snprintf(name, sizeof name, "msntt::PassKernelK<%s, %s, %d, %d>", fld, (sub & 64) ? "true" : "false", sub & 15, (sub & 16) ? 512 : 256);
       snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"alg_bytes\": %.0f}", first ? "" : ", ", name, sub_cnt[sub], kv.second, sub_by[sub]);
@@ -277,7 +289,7 @@ template <class F> struct Ctx : CtxBase {
   std::map<int, Plan*> plans;  // key = (log_n*4 + log_pad)*2 + inverse
   DevBuf ntt_scratch;
   int ntt_kmax = 9;            // largest tile (log2 rows) of a multi-pass plan; MS_NTT_KMAX overrides (tuning)
-  int ntt_v2 = 1, ntt_v2_min = 14, ntt_v2_maxpass = 2;   // MS_NTT_V2=0: round-1 kernels only (A/B); transforms of at least 2^MS_NTT_V2_MIN points use the two-sub-round tiles
+  int ntt_v2 = 1, ntt_v2_min = 14, ntt_v2_maxpass = 2, ntt_v2_sub3 = 1, ntt_v2_wide = 0;   // MS_NTT_V2=0: round-1 kernels only (A/B); transforms of at least 2^MS_NTT_V2_MIN points use the two-sub-round tiles
   int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1, ntt_fast = 1, ntt_fast_min = 22, ntt_fast_max = 24;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
 
   // log_pad: the input is zero beyond n >> log_pad
@@ -296,7 +308,10 @@ template <class F> struct Ctx : CtxBase {
       if (P <= ntt_v2_maxpass && m / P >= 7) {   // measured (r02): two passes of 2^10-row tiles beat three of 2^8; with three or more passes the round-1 tiles win
         use_v2 = true;
         pl->log_rho = 0; pl->log_r0 = log_pad; pl->npass = P;
-        for (int i = 0; i < P; i++) { pl->K[i] = m / P + (i < m % P ? 1 : 0); pl->LC[i] = (i == 0 && log_pad) ? 3 : v2_lc; pl->v2[i] = true; }
+        for (int i = 0; i < P; i++) {
+          pl->K[i] = m / P + (i < m % P ? 1 : 0); pl->LC[i] = (i == 0 && log_pad) ? 3 : v2_lc; pl->v2[i] = true;
+          if (F::ID == 0 && ntt_v2_wide && i > 0 && pl->K[i] == 10) pl->LC[i] = 4;   // later passes: 128-byte runs, one 1024-thread workgroup per CU
+        }
       }
     }
     if (use_v2) {}
@@ -386,12 +401,35 @@ template <class F> struct Ctx : CtxBase {
     next_sub = K | (TH == 512 ? 16 : 0) | (INV ? 64 : 0);
     return run<KK>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, TH, KK::lds_bytes(), pp);
   }
+  template <bool INV, int K, int LC, int MODE>
+  int launch_v2m(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
+    if constexpr (F::ID == 0 && K == 10 && LC == 4 && MODE == 1) {   // 16 columns x 1024 rows: 1024 threads, one workgroup per CU
+      typedef msntt::PassKernel2<F, GLM, INV, K, LC, 1024, 3, MODE> KK;
+      if (!KK::applicable(pp)) return 998;
+      next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | 2048 | (MODE << 12);
+      return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch) > 256 ? 256 : coop_grid(tiles * batch), 1024, KK::lds_bytes(), pp);
+    }
+    if constexpr (F::ID == 0 && K == 10 && LC == 3) {
+      if (ntt_v2_sub3) {   // 512 threads, three sub-rounds, exec-masked arithmetic: 16 waves per CU
+        typedef msntt::PassKernel2<F, GLM, INV, K, LC, 512, 3, MODE> KK;
+        if (!KK::applicable(pp)) return 998;
+        next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | 2048 | (MODE << 12);
+        return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch), 512, KK::lds_bytes(), pp);
+      }
+    }
+    typedef msntt::PassKernel2<F, typename msntt::NttArith<F>::type, INV, K, LC, 256, 2, MODE> KK;
+    if (!KK::applicable(pp)) return 998;   // NTT plan / PassKernel2 mismatch (a bug, not a runtime condition)
+    next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | (MODE << 12);
+    return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch), 256, KK::lds_bytes(), pp);
+  }
+  // persistent grid of the cooperative pass kernels: two workgroups per CU (their 72-80 KiB of LDS), a multiple of 8 (XCD-aware tile walk)
+  int ntt_coop_wgs = 512;
+  unsigned coop_grid(size_t work_items) const { return (unsigned)(work_items < (size_t)ntt_coop_wgs ? work_items : (size_t)ntt_coop_wgs); }
   template <bool INV, int K, int LC>
   int launch_v2(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
-    typedef msntt::PassKernel2<F, INV, K, LC, 256> KK;
-    if (!KK::applicable(pp)) return 998;   // NTT plan / PassKernel2 mismatch (a bug, not a runtime condition)
-    next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0);
-    return run<KK>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, 256, KK::lds_bytes(), pp);
+    if (pp.log_r0) { if constexpr (LC == 3) return launch_v2m<INV, K, LC, 2>(pp, tiles, batch); else return 996; }
+    if (pp.log_Rp == 0) return launch_v2m<INV, K, LC, 0>(pp, tiles, batch);
+    return launch_v2m<INV, K, LC, 1>(pp, tiles, batch);
   }
   template <bool INV, int LC>
   int launch_v2k(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
@@ -406,7 +444,7 @@ template <class F> struct Ctx : CtxBase {
   template <bool INV>
   int launch_pass(const msntt::PassParams<F>& pp, size_t tiles, size_t batch, bool v2 = false) {
     if (v2) {
-      if constexpr (F::ID == 0) return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : 997;
+      if constexpr (F::ID == 0) return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : (pp.log_r == 10 && pp.log_C == 4 ? launch_v2<INV, 10, 4>(pp, tiles, batch) : 997);
       else return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : launch_v2k<INV, 4>(pp, tiles, batch);
     }
     // compile-time specialised tiles for the large transforms (no virtual pass, 16 columns)
@@ -475,7 +513,7 @@ template <class F> struct Ctx : CtxBase {
       pp.log_r0 = (k == 0) ? log_r0 : 0; pp.log_rho = (k == 0) ? pl->log_rho : 0;
       const int cols_log = log_n - pl->K[k];
       pp.log_C = cols_log < pl->LC[k] ? cols_log : pl->LC[k];
-      pp.last = (k == P - 1);
+      pp.last = (k == P - 1); pp.nbatch = (u32)batch;
       const size_t tiles = ((size_t)1 << cols_log) >> pp.log_C;
       next_bytes = (double)(n_in + n) * batch * sizeof(T) / P;  // (n_in + n)*s per transform, shared by its P real passes
       if (inverse) CK(launch_pass<true>(pp, tiles, batch, pl->v2[k])); else CK(launch_pass<false>(pp, tiles, batch, pl->v2[k]));
@@ -641,6 +679,9 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_TH512")) ntt_th512 = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
     if (const char* e = getenv("MS_NTT_V2")) ntt_v2 = atoi(e);
+    if (const char* e = getenv("MS_NTT_V2_SUB3")) ntt_v2_sub3 = atoi(e);
+    if (const char* e = getenv("MS_NTT_V2_WIDE")) ntt_v2_wide = atoi(e);
+    if (const char* e = getenv("MS_NTT_COOP_WGS")) { int v = atoi(e); if (v >= 8 && v <= 65536) ntt_coop_wgs = v & ~7; }
     if (const char* e = getenv("MS_NTT_V2_MAXPASS")) { int v = atoi(e); if (v >= 1 && v <= 4) ntt_v2_maxpass = v; }
     if (const char* e = getenv("MS_NTT_V2_MIN")) { int v = atoi(e); if (v >= 12 && v <= 32) ntt_v2_min = v; }
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);

@@ -68,6 +68,7 @@ template <class F> struct PassParams {
   u32 log_n, log_r, log_Rp, log_C, lo_bits;
   u32 log_r0 /* >0: this pass loads through a virtual r0-point pass */, log_rho /* of whose inputs 2^log_rho blocks are non-zero */;
   u32 last;
+  u32 nbatch;                       // batch entries of the launch (cooperative kernels walk batch x tiles themselves)
 };
 
 // ---- Goldilocks shift twiddles ------------------------------------------------
@@ -87,12 +88,12 @@ template <int S> MS_HD u64 gl_mul_pow2_v1(u64 x) {
   }
 }
 // throughput formulation (arithmetic class GLT): every step canonical and branch-free on sign bits
-template <int S> MS_HD u64 gl_mul_pow2(u64 x) {
+template <int S, class A = GLT> MS_HD u64 gl_mul_pow2(u64 x) {
   static_assert(S >= 0 && S < 96, "shift out of range");
   if constexpr (S == 0) return x;
-  else if constexpr (S < 32) return GLT::fold_small(ms_pin64(x << S), GL::hi(x) >> (32 - S));  // the S bits shifted out times 2^64 == EPS (pinned: one v_lshlrev_b64, its high word reused)
-  else if constexpr (S < 64) return GLT::mul_x32(gl_mul_pow2<S - 32>(x));                       // two steps: both stay canonical
-  else return GLT::mul_x64(gl_mul_pow2<S - 64>(x));
+  else if constexpr (S < 32) return A::fold_small(ms_pin64(x << S), GL::hi(x) >> (32 - S));  // the S bits shifted out times 2^64 == EPS (pinned: one v_lshlrev_b64, its high word reused)
+  else if constexpr (S < 64) return A::mul_x32(gl_mul_pow2<S - 32, A>(x));                    // two steps: both stay canonical
+  else return A::mul_x64(gl_mul_pow2<S - 64, A>(x));
 }
 // (a - b) * w_(2^LOG2H2)^J for the reference's roots: w_64 = 2^39 (forward), 2^153 (inverse)
 template <class F, bool INV, int LOG2H2, int J> struct TwMul;
@@ -112,16 +113,26 @@ template <bool INV, int LOG2H2, int J> struct TwMul<GLT, INV, LOG2H2, J> {
     else return gl_mul_pow2<EXP>(GLT::sub(a, b));
   }
 };
+template <bool INV, int LOG2H2, int J> struct TwMul<GLM, INV, LOG2H2, J> {
+  static constexpr int EXP = ((INV ? 153 : 39) * (64 >> LOG2H2) * J) % 192;
+  static MS_HD u64 diff_mul(u64 a, u64 b, const u64* w_r, int log_r) {
+    (void)w_r; (void)log_r;
+    if constexpr (EXP >= 96) return gl_mul_pow2<EXP - 96, GLM>(GLM::sub(b, a));
+    else return gl_mul_pow2<EXP, GLM>(GLM::sub(a, b));
+  }
+};
 template <bool INV, int LOG2H2, int J> struct TwMul<BB, INV, LOG2H2, J> {
   static MS_HD u32 diff_mul(u32 a, u32 b, const u32* w_r, int log_r) { return BB::mul_tw(BB::sub(a, b), w_r[(size_t)J << (log_r - LOG2H2)]); }
 };
 // arithmetic class of the round-2 tiles: the throughput formulation where the field has one
 template <class F> struct NttArith { typedef F type; };
-#ifndef MS_NTT_GLT
-#define MS_NTT_GLT 1
+#ifndef MS_NTT_ARITH
+#define MS_NTT_ARITH 1   // 0: GL (compare + select)  1: GLT (sign bits)  2: GLM (exec-masked asm; wants >= 4 waves per SIMD)
 #endif
-#if MS_NTT_GLT
+#if MS_NTT_ARITH == 1
 template <> struct NttArith<GL> { typedef GLT type; };
+#elif MS_NTT_ARITH == 2
+template <> struct NttArith<GL> { typedef GLM type; };
 #endif
 
 template <class F, bool INV, int B, int S, int BLK, int J> struct DifStage {
@@ -426,43 +437,52 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
 
 // ---------------------------------------------------------------------------------------------
 // PassKernel2: the large-transform pass of round 2.  A tile of 2^K rows x 2^LC columns (GL: 2^10 x 8 = 64 KiB, two workgroups per
-// CU) is transformed by TWO register sub-rounds of radix 2^B1 and 2^B2 (B1 = ceil(K/2) <= 5, B2 = K - B1): one general twiddle
-// multiplication inside the tile instead of two, ten butterfly stages per HBM pass instead of eight, so that a 2^20-point transform
-// (and, behind the virtual radix-8 zero-padding pass, the 2^23-point LDE of 2^20 coefficients) is TWO passes instead of three.
+// CU) is transformed by NSUB register sub-rounds, so that a 2^20-point transform (and, behind the virtual radix-8 zero-padding
+// pass, the 2^23-point LDE of 2^20 coefficients) is TWO HBM passes of ten butterfly stages instead of three of eight.
 // Measured background (tools/ntt_lab.hip, profiles/r02_ntt_lab.log): these kernels are bound by the NUMBER of VALU instructions
-// (~3.3-3.6 issue cycles each, whatever the opcode), an exec-masked formulation of the field arithmetic needs >= 4 waves per SIMD to
-// pay, and a 64 KiB tile leaves 2: hence compiler-scheduled sign-bit arithmetic (field.hpp) with 32 independent butterflies per thread.
-//
+// (3.3-3.6 issue cycles each whatever the opcode) and by how many waves hide each other's stalls:
+//   NSUB = 2, 256 threads, arithmetic class GLT: radix-32 x radix-32 per thread, one twiddle multiplication inside the tile,
+//             compiler-scheduled sign-bit arithmetic (tolerates the 2 waves per SIMD the 64 KiB tile leaves)
+//   NSUB = 3, 512 threads, arithmetic class GLM: radix-16 x 8 x 8, 16 waves per CU - the occupancy the exec-masked arithmetic
+//             (7.8 instead of 11.7 VALU instructions per element-stage) needs; one more twiddle multiplication and LDS round trip.
 // Global access is 16 bytes per lane (global_load/store_dwordx4: VEC = 2 Goldilocks / 4 BabyBear elements), a tile row is one
-// 64-byte run.  LDS: element (row, c) at row*C + c + (row >> B2)*PADE; PADE makes the three access patterns conflict-free
-// (sub-round 1: lanes over (lo, c), c fastest; sub-round 2: lanes over hi; row-wise load/store sweeps).
-// The w_r table (sub-round 1) and the per-row store twiddles (store phase) share one LDS region.
+// 64-byte run.  LDS: element (row, c) at prow(row)*C + c with prow(row) = row ^ ((row >> BL) & 3), BL = bits of the last digit:
+// the XOR spreads the four row groups a half-wave touches in the last sub-round over all banks (no padding, 16-byte alignment kept),
+// and permutes rows only inside aligned groups of four, which the other access patterns (lanes over consecutive rows x columns)
+// do not notice.  The w_r table (sub-round twiddles) and the per-row store twiddles share one LDS region for Goldilocks.
 // Cases (same index algebra as PassKernel above):
 //   log_r0 == 0, log_Rp == 0   first pass of a plain transform: transposed store, twiddle w_n^(i_new * f)
 //   log_r0 == 0, log_Rp >= LC  later pass: 64-byte output runs, one twiddle per tile row (none in the last pass)
 //   log_r0 == LC (GL: 3)       first pass behind the virtual zero-padding pass: the C columns of a tile are the r0 cosets of ONE
 //                              coefficient index, the tile's output is one contiguous block of r0 * r elements
-template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
+template <int K, int NSUB> struct Digits2 {
+  // digit sizes, top digit first: NSUB == 2: (ceil(K/2), floor(K/2)); NSUB == 3: (K - 2*(K/3), K/3, K/3)
+  static constexpr int bits(int s) { return NSUB == 2 ? (s == 0 ? (K + 1) / 2 : K / 2) : (s == 0 ? K - 2 * (K / 3) : K / 3); }
+  static constexpr int slo(int s) { int d = 0; for (int t = 0; t <= s; t++) d += bits(t); return K - d; }
+};
+// MODE (compile time, so that each instance carries one load and one store path): 0 first pass of a plain transform,
+// 1 later pass, 2 first pass behind the virtual zero-padding pass
+template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE> struct PassKernel2 {
   typedef typename F::T T;
-  typedef typename NttArith<F>::type A;   // arithmetic class (same values as F's, formulated for throughput)
   typedef PassParams<F> Params;
+  typedef Digits2<K, NSUB> DG;
   static constexpr int THREADS = TH;
   static constexpr int R = 1 << K, C = 1 << LC;
-  static constexpr int B1 = (K + 1) / 2, B2 = K - B1, Q1 = 1 << B2;   // sub-round 1: top B1 row bits (distance Q1), sub-round 2: low B2 bits
-  static constexpr int PADE = (B1 >= 5) ? 1 : (32 >> B1);
+  static constexpr int BL = DG::bits(NSUB - 1);
   static constexpr int VEC = 16 / (int)sizeof(T), LPR = C / VEC, RPS = TH / LPR, SWEEPS = R / RPS;  // lanes per row, rows per sweep
-  static constexpr int ITEMS1 = (R >> B1) * C, ITEMS2 = (R >> B2) * C;
-  static_assert(K >= 7 && K <= 10 && B1 <= 5 && C % VEC == 0 && TH % LPR == 0 && R % RPS == 0, "unsupported tile");
-  static_assert(ITEMS1 % TH == 0 || ITEMS1 < TH, "items");
-  struct alignas(16) V16 { T v[VEC]; };
+  static constexpr int MIN_WAVES = (TH >= 512) ? 4 : 2;    // waves per SIMD the register allocator must leave room for (16 waves per CU: 2 x 512 or 1 x 1024 threads)
+  static_assert(K >= 7 && K <= 10 && DG::bits(0) <= 5 && BL >= 2 && C % VEC == 0 && TH % LPR == 0 && R % RPS == 0 && (NSUB == 2 || NSUB == 3), "unsupported tile");
+  static_assert(NSUB == 2 || DG::bits(1) >= 2, "middle digit");
+  typedef T V16 __attribute__((vector_size(16)));   // one 16-byte global / LDS access; a native vector, so that prefetched rows stay in registers
 
-  static MS_HD int nphases(const Params&) { return 4; }
-  static MS_HD size_t tile_elems() { return (size_t)R * C + (size_t)(R >> B2) * PADE; }
-  static constexpr bool SHARE_W = (F::ID == 0);   // Goldilocks: the store twiddles reuse the w_r region (BabyBear's sub-round 2 still reads w_r)
-  static MS_HD size_t lds_bytes() { return (tile_elems() + (SHARE_W ? R : 2 * R)) * sizeof(T); }
-  static MS_HD int tix(int row, int c) { return row * C + c + (row >> B2) * PADE; }
+  // tile | w_r [R] | store twiddle of every tile row [R] (filled in the load phase, while the tile's global loads are in flight)
+  static MS_HD size_t lds_bytes() { return ((size_t)R * C + 2 * R) * sizeof(T); }
+  static MS_HD int prow(int row) { return row ^ ((row >> BL) & 3); }
+  static MS_HD int tix(int row, int c) { return prow(row) * C + c; }
+  static MS_HD int mode_of(const Params& p) { return p.log_r0 ? 2 : (p.log_Rp == 0 ? 0 : 1); }
   static MS_HD bool applicable(const Params& p) {
-    return p.log_r == K && p.log_C == LC && p.log_rho == 0 && ((p.log_r0 == 0 && (p.log_Rp == 0 || p.log_Rp >= LC)) || (p.log_r0 == LC && p.log_Rp == LC));
+    return p.log_r == K && p.log_C == LC && p.log_rho == 0 && mode_of(p) == MODE &&
+           ((p.log_r0 == 0 && (p.log_Rp == 0 || p.log_Rp >= LC)) || (p.log_r0 == LC && p.log_Rp == LC));
   }
   static MS_DEV T tw_global(const Params& p, size_t e) {
     T tw = p.tw_lo[e & (((size_t)1 << p.lo_bits) - 1)];
@@ -470,150 +490,214 @@ template <class F, bool INV, int K, int LC, int TH> struct PassKernel2 {
     if (eh) tw = A::mul_tw(tw, p.tw_hi[eh]);
     return tw;
   }
-  // logical tile of workgroup bx.  Behind the virtual pass the 2^LC... tiles that share 64-byte source lines are neighbours: give each
-  // XCD (workgroups are dealt round-robin over the 8 XCDs) a contiguous range of tiles so that those lines are fetched into ONE L2.
-  static MS_DEV size_t tile_of(const Params& p, int bx) {
-    const size_t tiles = ((size_t)1 << (p.log_n - K)) >> LC;
-    if (p.log_r0 && tiles >= 64) return (size_t)(bx & 7) * (tiles >> 3) + (size_t)(bx >> 3);
-    return (size_t)bx;
+  // output digit index <-> tile row (digit-reversed): the digit taken from the top of the row index is the LOWEST output digit
+  static MS_HD int row_to_inew(int row) {
+    int inew = 0, done = 0;
+    for (int s = 0; s < NSUB; s++) { const int b = DG::bits(s); inew |= ((row >> (K - done - b)) & ((1 << b) - 1)) << done; done += b; }
+    return inew;
+  }
+  static MS_HD int inew_to_row(int inew) {
+    int row = 0, done = 0;
+    for (int s = 0; s < NSUB; s++) { const int b = DG::bits(s); row |= ((inew >> done) & ((1 << b) - 1)) << (K - done - b); done += b; }
+    return row;
   }
 
-  template <int B, int J> static MS_DEV void sub1_items(int tid, T* tile, const T* w) {
-    constexpr int NJ = (ITEMS1 + TH - 1) / TH;
+  // one sub-round: digit of B bits at row bits [SLO, SLO + B); item g = the other row bits (hi:lo packed), c = column
+  template <int SR, int J> static MS_DEV void sub_items(int tid, T* tile, const T* w) {
+    constexpr int B = DG::bits(SR), SLO = DG::slo(SR), Q = 1 << SLO;
+    constexpr int ITEMS = (R >> B) * C, NJ = (ITEMS + TH - 1) / TH;
+    constexpr bool LAST = (SR == NSUB - 1);
+    static_assert(SLO >= BL + 2 || SLO == BL || SLO == 0, "digit position vs the row swizzle");
     const int it = tid + J * TH;
-    if (ITEMS1 >= TH || it < ITEMS1) {
-      const int c = it & (C - 1), lo = it >> LC;             // lanes: c fastest
-      T* base = tile + lo * C + c;                            // row lo + t*Q1: + t*(Q1*C + PADE)
+    if (ITEMS % TH == 0 || it < ITEMS) {
+      const int c = it & (C - 1), g = it >> LC;
+      const int lo = g & (Q - 1), R0 = ((g >> SLO) << (SLO + B)) | lo;     // row of t = 0
+      // physical row of element t = R0 + t*Q under the swizzle: up to four bases selected by the compile-time (t & 3)
+      T* base[4];
+      if constexpr (SLO >= BL + 2) { base[0] = tile + ((R0 ^ ((R0 >> BL) & 3)) * C + c); base[1] = base[2] = base[3] = base[0]; }
+      else if constexpr (SLO == 0) { const int h3 = (R0 >> BL) & 3; for (int k = 0; k < 4; k++) base[k] = tile + ((R0 + (k ^ h3)) * C + c); }
+      else { for (int k = 0; k < 4; k++) base[k] = tile + ((R0 ^ k) * C + c); }                // SLO == BL: the swizzle term is t & 3
       T x[1 << B];
 #pragma unroll
-      for (int t = 0; t < (1 << B); t++) x[t] = base[t * (Q1 * C + PADE)];
+      for (int t = 0; t < (1 << B); t++) x[t] = base[t & 3][(SLO == 0 ? (t & ~3) : t * Q) * C];
       dif_regs<A, INV, B>(x, w, K);
 #pragma unroll
       for (int e = 0; e < (1 << B); e++) {
         T v = x[bitrev(e, B)];
-        if (e != 0) v = A::mul_tw(v, w[e * lo]);              // w_r^(e * lo); lo == 0 multiplies by w[0] = 1
-        base[e * (Q1 * C + PADE)] = v;
+        if constexpr (!LAST) { if (e != 0) v = A::mul_tw(v, w[(e * lo) << (K - SLO - B)]); }   // w_{Q 2^B}^(e * lo); lo == 0 multiplies by w[0] = 1
+        base[e & 3][(SLO == 0 ? (e & ~3) : e * Q) * C] = v;
       }
     }
-    if constexpr (J + 1 < NJ) sub1_items<B, J + 1>(tid, tile, w);
-  }
-  template <int B, int J> static MS_DEV void sub2_items(int tid, T* tile, const T* w) {
-    constexpr int NJ = (ITEMS2 + TH - 1) / TH;
-    const int it = tid + J * TH;
-    if (ITEMS2 >= TH || it < ITEMS2) {
-      const int hi = it & ((1 << B1) - 1), c = it >> B1;      // lanes: hi fastest
-      T* base = tile + hi * (Q1 * C + PADE) + c;              // row hi*Q1 + t: + t*C
-      T x[1 << B];
-#pragma unroll
-      for (int t = 0; t < (1 << B); t++) x[t] = base[t * C];
-      dif_regs<A, INV, B>(x, w, K);
-#pragma unroll
-      for (int e = 0; e < (1 << B); e++) base[e * C] = x[bitrev(e, B)];
-    }
-    if constexpr (J + 1 < NJ) sub2_items<B, J + 1>(tid, tile, w);
+    if constexpr (J + 1 < NJ) sub_items<SR, J + 1>(tid, tile, w);
   }
 
-  static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int, unsigned char* lds) {
-    T* tile = reinterpret_cast<T*>(lds);
-    T* w = tile + tile_elems();                  // [R]: w_r (phases 0-1), then the store twiddle of every tile row (phases 2-3)
-    const size_t n = (size_t)1 << p.log_n, cs = n >> K;
-    const size_t f0 = tile_of(p, bx) << LC;
-    const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
-    if (ph == 0) {
-      const T* src = p.src + (size_t)by * p.src_bstride;
-      if (p.log_r0 == 0) {
-        if (p.n_in >= n) {
-          V16 buf[SWEEPS];
-          const T* s0 = src + f0 + c0 + (size_t)rb * cs;
+  // ---- cooperative, persistent form: a workgroup walks tiles g = bx, bx + nbx, ... of the nbatch * tiles of the launch, and the
+  // global loads of its NEXT tile are issued into registers right after the first sub-round, so that they are in flight during the
+  // remaining sub-rounds and the store of the current one.  Measured before this change (profiles/r02_*): with a load burst at the
+  // start of every tile and two workgroups per CU the waves sat in s_waitcnt / s_barrier 60 % of the time and the CU kept ~17 KiB of
+  // loads in flight on average - a latency bound at 2.9 TB/s with the VALU 15 % busy.
+  // Cross-tile prefetch: measured on MI355X (r02) it does NOT pay - the 32 registers it holds across the sub-rounds push the kernel over
+  // its 128-VGPR budget (spills, whose scratch traffic shares the vector-memory counter with the prefetch), and with it fitted (later
+  // passes: 13 spills, all outside the prefetch window) the pass still took 323 us instead of 298: the memory path alone (no
+  // sub-rounds) needs 220 us, the arithmetic alone 187 us, and two workgroups per CU already overlap most of the two.
+#ifndef MS_NTT_PREFETCH
+#define MS_NTT_PREFETCH 0
+#endif
+  static constexpr bool PREFETCH = MS_NTT_PREFETCH != 0;
+  static constexpr int NROWS = (MODE == 2) ? 1 : SWEEPS, NXS = (MODE == 2) ? (R * C / TH) : 1;   // prefetch registers: whole 16-byte row pieces or, behind the virtual pass, single coefficients
+  static MS_DEV void locate(size_t g, size_t tiles, size_t* tile, size_t* by) { *by = g / tiles; *tile = g - *by * tiles; }
+  // issues the global loads of one work item into the caller's registers (fully unrolled: `rows` / `xs` never leave the register file)
+  static MS_DEV void prefetch(const Params& p, size_t tile, size_t by, int tid, V16 (&rows)[NROWS], T (&xs)[NXS]) {
+    const size_t n = (size_t)1 << p.log_n, cs = n >> K, f0 = tile << LC;
+    const T* src = p.src + by * p.src_bstride;
+    if constexpr (MODE != 2) {
+      const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
+      const T* s0 = src + f0 + c0 + (size_t)rb * cs;
+      if (MODE == 1 || p.n_in >= n) {
 #pragma unroll
-          for (int i = 0; i < SWEEPS; i++) buf[i] = *reinterpret_cast<const V16*>(s0 + (size_t)(i * RPS) * cs);
+#ifdef MS_ABL_NOMEM
+        for (int i = 0; i < SWEEPS; i++) { V16 z; for (int v = 0; v < VEC; v++) z[v] = (T)(tid + i + v); rows[i] = z; }
+#else
+        for (int i = 0; i < SWEEPS; i++) rows[i] = *reinterpret_cast<const V16*>(s0 + (size_t)(i * RPS) * cs);
+#endif
+      } else {
 #pragma unroll
-          for (int i = 0; i < SWEEPS; i++) {
-            T* d = tile + tix(rb + i * RPS, c0);
+        for (int i = 0; i < SWEEPS; i++) {
+          const size_t a = f0 + c0 + (size_t)(rb + i * RPS) * cs;
 #pragma unroll
-            for (int v = 0; v < VEC; v++) d[v] = buf[i].v[v];
-          }
-        } else {
-          for (int i = 0; i < SWEEPS; i++) {
-            const size_t a = f0 + c0 + (size_t)(rb + i * RPS) * cs;
-            T* d = tile + tix(rb + i * RPS, c0);
-            for (int v = 0; v < VEC; v++) d[v] = (a + v < p.n_in) ? src[a + v] : (T)0;
-          }
+          for (int v = 0; v < VEC; v++) rows[i][v] = (a + v < p.n_in) ? s0[(size_t)(i * RPS) * cs + v] : (T)0;
         }
+      }
+    } else {
+      const size_t k2 = f0 >> LC, nprime = n >> (LC + K);
+#pragma unroll
+      for (int j = 0; j < NXS; j++) {
+        const int row = (tid + j * TH) >> LC;
+        const size_t k = k2 + nprime * (size_t)row;
+        xs[j] = (k < p.n_in) ? src[k] : (T)0;
+      }
+    }
+  }
+  static MS_DEV void run(const Params& p, int bx, int, int nbx, int tid, unsigned char* lds) {
+    T* tile = reinterpret_cast<T*>(lds);
+    T* w = tile + (size_t)R * C;                 // [R]: w_r (sub-round twiddles), loaded once per workgroup
+    T* twr = w + R;                              // [R]: store twiddle of every tile row
+    const size_t tiles = ((size_t)1 << (p.log_n - K)) >> LC, total = tiles * (size_t)p.nbatch;
+    const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
+    const bool do_scale = p.do_scale != 0;
+    // work items of this workgroup: g(i) for i = 0, 1, ..; behind the virtual pass XCD x = bx & 7 walks the contiguous range
+    // [x * total / 8, (x + 1) * total / 8) (its workgroups share 64-byte source lines through that XCD's L2)
+    const bool xcd_map = MODE == 2 && (nbx & 7) == 0 && (total & 7) == 0 && total >= 64;
+    const size_t stride = xcd_map ? (size_t)(nbx >> 3) : (size_t)nbx, first = xcd_map ? (size_t)(bx >> 3) : (size_t)bx;
+    const size_t lim = xcd_map ? (total >> 3) : total, base_g = xcd_map ? (size_t)(bx & 7) * (total >> 3) : 0;
+    if (first >= lim) return;
+    for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
+    V16 rows[NROWS]; T xs[NXS];
+    size_t tl, by;
+    locate(base_g + first, tiles, &tl, &by);
+    if (PREFETCH) prefetch(p, tl, by, tid, rows, xs);
+    for (size_t it = first; it < lim; it += stride) {
+      locate(base_g + it, tiles, &tl, &by);
+      if (!PREFETCH && MODE != 2) prefetch(p, tl, by, tid, rows, xs);
+      const size_t f0 = tl << LC;
+      const bool row_tw = MODE != 0 && !p.last && (f0 >> p.log_Rp) != 0;
+      // ---- the prefetched inputs go to LDS (behind the virtual pass: times w_(r0 r)^(i1 * row)); the row twiddles of this tile
+      if (row_tw) {
+        const size_t k_low = f0 >> p.log_Rp;
+        for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);   // w_n^(k_low * Rp * i_new)
+      }
+      if constexpr (MODE != 2) {
+#pragma unroll
+        for (int i = 0; i < SWEEPS; i++) *reinterpret_cast<V16*>(tile + tix(rb + i * RPS, c0)) = rows[i];
       } else {
         // virtual r0-point pass (r0 = C, only the first n/r0 inputs non-zero): A_1[k2*r0 + i1] = w_n^(i1*k) x[k], k = k2 + nprime*row.
         // The k2 part of the twiddle rides on the store twiddle; here x[k] * w_(r0 r)^(i1 * row).  One lane per tile element.
-        const size_t k2 = f0 >> LC, nprime = n >> (LC + K);
-        for (int idx = tid; idx < R * C; idx += TH) {
-          const int row = idx >> LC, i1 = idx & (C - 1);
-          const size_t k = k2 + nprime * (size_t)row;
-          T v = (k < p.n_in) ? src[k] : (T)0;
-          if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
-          tile[tix(row, i1)] = v;
-        }
-      }
-      for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
-      return;
-    }
-    if (ph == 1) { sub1_items<B1, 0>(tid, tile, w); return; }
-    T* twr = w + (SHARE_W ? 0 : R);                  // [R] store twiddle of every tile row
-    const bool row_tw = !p.last && p.log_Rp >= LC && (f0 >> p.log_Rp) != 0;
-    if (ph == 2) {
-      if (row_tw) {                                  // Goldilocks: w_r is dead after sub-round 1 (its in-register twiddles are shifts)
-        const size_t k_low = f0 >> p.log_Rp;
-        for (int row = tid; row < R; row += TH) {
-          const int inew = (row >> B2) | ((row & (Q1 - 1)) << B1);
-          twr[row] = tw_global(p, ((size_t)inew * k_low) << p.log_Rp);   // w_n^(k_low * Rp * i_new)
-        }
-      }
-      sub2_items<B2, 0>(tid, tile, w);
-      return;
-    }
-    // ---- store phase
-    T* dst = p.dst + (size_t)by * p.dst_bstride;
-    const bool do_scale = p.do_scale != 0;
-    if (p.log_Rp >= LC) {
-      // out = k_low*Rp*r + i_done + Rp*i_new: a tile row is one 16*LPR-byte run
-      const size_t k_low = f0 >> p.log_Rp, i_done0 = (f0 & (((size_t)1 << p.log_Rp) - 1)) + c0;
-      T* out = dst + ((k_low << p.log_Rp) << K) + i_done0;
-      T gc[VEC];                                     // behind the virtual pass: w_n^(k_low * i_done), i_done = the column
-      const bool col_tw = row_tw && p.log_r0 != 0;
+        if (PREFETCH) {
 #pragma unroll
-      for (int v = 0; v < VEC; v++) gc[v] = col_tw ? tw_global(p, k_low * (size_t)(c0 + v)) : F::to_tw(F::from_u64(1));
+          for (int j = 0; j < NXS; j++) {
+            const int idx = tid + j * TH, row = idx >> LC, i1 = idx & (C - 1);
+            T v = xs[j];
+            if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
+            tile[tix(row, i1)] = v;
+          }
+        } else {
+          const size_t n = (size_t)1 << p.log_n, k2 = f0 >> LC, nprime = n >> (LC + K);
+          const T* src = p.src + by * p.src_bstride;
 #pragma unroll 4
-      for (int i = 0; i < SWEEPS; i++) {
-        const int row = rb + i * RPS;
-        const int inew = (row >> B2) | ((row & (Q1 - 1)) << B1);
-        const T* sp = tile + tix(row, c0);
-        const T rt = row_tw ? twr[row] : F::to_tw(F::from_u64(1));
-        V16 o;
-#pragma unroll
-        for (int v = 0; v < VEC; v++) {
-          T x = sp[v];
-          if (row_tw) x = A::mul_tw(x, rt);
-          if (col_tw && (c0 + v)) x = A::mul_tw(x, gc[v]);
-          if (do_scale) x = A::mul_tw(x, p.scale);
-          o.v[v] = x;
+          for (int idx = tid; idx < R * C; idx += TH) {
+            const int row = idx >> LC, i1 = idx & (C - 1);
+            const size_t k = k2 + nprime * (size_t)row;
+            T v = (k < p.n_in) ? src[k] : (T)0;
+            if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
+            tile[tix(row, i1)] = v;
+          }
         }
-        *reinterpret_cast<V16*>(out + ((size_t)inew << p.log_Rp)) = o;
       }
-    } else {
-      // first pass of a plain transform: out = f*r + i_new, i_new fastest across lanes
-      for (int idx = tid * VEC; idx < R * C; idx += TH * VEC) {
-        const int c = idx >> K, inew0 = idx & (R - 1);
-        const size_t f = f0 + c;
-        V16 o;
+      msrt::wg_barrier();
+#ifndef MS_ABL_NOCOMPUTE   // ablation builds (tools/ntt_ablate.sh): memory-only / compute-only timings of the same kernel
+      sub_items<0, 0>(tid, tile, w);
+#endif
+      msrt::wg_barrier();
+      if (PREFETCH && it + stride < lim) {   // next tile's loads: in flight during the remaining sub-rounds and the store
+        size_t ntl, nby;
+        locate(base_g + it + stride, tiles, &ntl, &nby);
+        prefetch(p, ntl, nby, tid, rows, xs);
+      }
+#ifndef MS_ABL_NOCOMPUTE
+      sub_items<1, 0>(tid, tile, w);
+#endif
+      msrt::wg_barrier();
+#ifndef MS_ABL_NOCOMPUTE
+      if constexpr (NSUB >= 3) { sub_items<2, 0>(tid, tile, w); msrt::wg_barrier(); }
+#endif
+      // ---- store
+      T* dst = p.dst + by * p.dst_bstride;
+      if constexpr (MODE != 0) {
+        // out = k_low*Rp*r + i_done + Rp*i_new: a tile row is one 16*LPR-byte run
+        const size_t k_low = f0 >> p.log_Rp, i_done0 = (f0 & (((size_t)1 << p.log_Rp) - 1)) + c0;
+        T* out = dst + ((k_low << p.log_Rp) << K) + i_done0;
+        T gc[VEC];                                     // behind the virtual pass: w_n^(k_low * i_done), i_done = the column
+        const bool col_tw = row_tw && MODE == 2;
 #pragma unroll
-        for (int v = 0; v < VEC; v++) {
-          const int inew = inew0 + v;
-          const int row = ((inew & ((1 << B1) - 1)) << B2) | (inew >> B1);
-          T x = tile[tix(row, c)];
-          if (!p.last) { const size_t e = (size_t)inew * f; if (e) x = A::mul_tw(x, tw_global(p, e)); }
-          if (do_scale) x = A::mul_tw(x, p.scale);
-          o.v[v] = x;
+        for (int v = 0; v < VEC; v++) gc[v] = col_tw ? tw_global(p, k_low * (size_t)(c0 + v)) : F::to_tw(F::from_u64(1));
+#pragma unroll 2
+        for (int i = 0; i < SWEEPS; i++) {
+          const int row = rb + i * RPS;
+          const int inew = row_to_inew(row);
+          V16 o = *reinterpret_cast<const V16*>(tile + tix(row, c0));
+          const T rt = row_tw ? twr[row] : F::to_tw(F::from_u64(1));
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            T x = o[v];
+            if (row_tw) x = A::mul_tw(x, rt);
+            if (col_tw && (c0 + v)) x = A::mul_tw(x, gc[v]);
+            if (do_scale) x = A::mul_tw(x, p.scale);
+            o[v] = x;
+          }
+#ifdef MS_ABL_NOMEM
+          if (o[0] == 0x1234567 && tid == 777) *reinterpret_cast<V16*>(out + ((size_t)inew << p.log_Rp)) = o;   // keeps the computation alive, stores (almost) nothing
+#else
+          *reinterpret_cast<V16*>(out + ((size_t)inew << p.log_Rp)) = o;
+#endif
         }
-        *reinterpret_cast<V16*>(dst + (f << K) + inew0) = o;
+      } else {
+        // first pass of a plain transform: out = f*r + i_new, i_new fastest across lanes
+        for (int idx = tid * VEC; idx < R * C; idx += TH * VEC) {
+          const int c = idx >> K, inew0 = idx & (R - 1);
+          const size_t f = f0 + c;
+          V16 o;
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const int inew = inew0 + v;
+            T x = tile[tix(inew_to_row(inew), c)];
+            if (!p.last) { const size_t e = (size_t)inew * f; if (e) x = A::mul_tw(x, tw_global(p, e)); }
+            if (do_scale) x = A::mul_tw(x, p.scale);
+            o[v] = x;
+          }
+          *reinterpret_cast<V16*>(dst + (f << K) + inew0) = o;
+        }
       }
+      msrt::wg_barrier();   // the tile and its row twiddles are free for the next work item
     }
   }
 };

@@ -66,6 +66,61 @@ struct Rccl {
   static Rccl& get() { static Rccl r; return r; }
   int load() { return 1; }
 };
+}  // namespace msrt
+// ---- cooperative kernels (K::run with workgroup barriers INSIDE the function, per-thread state alive across them): every thread of a
+// workgroup is a fiber (ucontext); wg_barrier() yields to the scheduler, which resumes the fibers round-robin, so all of them reach
+// barrier k before any runs past it.  wave_shfl_xor() & co. are workgroup-wide rendezvous points of the same kind that exchange
+// values inside each group of 64 consecutive threads - the emulated wave is 64 lanes wide, like the hardware's.
+#include <ucontext.h>
+namespace msrt {
+struct FiberBlock {
+  static constexpr size_t STACK = 96 << 10;
+  std::vector<ucontext_t> ctx; std::vector<unsigned char> stacks; std::vector<char> done; std::vector<unsigned long long> xchg;
+  ucontext_t sched; int cur = -1, nthreads = 0;
+  void (*entry)(void*, int) = nullptr; void* arg = nullptr;
+  static FiberBlock*& active() { static thread_local FiberBlock* a = nullptr; return a; }
+  static void trampoline() { FiberBlock* b = active(); const int t = b->cur; b->entry(b->arg, t); b->done[t] = 1; swapcontext(&b->ctx[t], &b->sched); }
+  void yield() { const int t = cur; swapcontext(&ctx[t], &sched); }
+  void run_block(int threads, void (*fn)(void*, int), void* a) {
+    nthreads = threads; entry = fn; arg = a;
+    if ((int)ctx.size() < threads) { ctx.resize(threads); stacks.resize((size_t)threads * STACK); }
+    done.assign(threads, 0); xchg.assign(threads, 0);
+    for (int t = 0; t < threads; t++) {
+      getcontext(&ctx[t]);
+      ctx[t].uc_stack.ss_sp = stacks.data() + (size_t)t * STACK; ctx[t].uc_stack.ss_size = STACK; ctx[t].uc_link = &sched;
+      makecontext(&ctx[t], (void (*)())trampoline, 0);
+    }
+    FiberBlock* prev = active(); active() = this;
+    for (;;) {
+      bool any = false;
+      for (int t = 0; t < threads; t++) if (!done[t]) { any = true; cur = t; swapcontext(&sched, &ctx[t]); }
+      if (!any) break;
+    }
+    cur = -1; active() = prev;
+  }
+};
+inline void wg_barrier() { FiberBlock::active()->yield(); }
+// value of lane (lane ^ mask) of the caller's 64-lane wave; every thread of the workgroup must call it (like __shfl_xor under full exec)
+inline unsigned long long wave_shfl_xor(unsigned long long v, int mask) {
+  FiberBlock* b = FiberBlock::active(); const int t = b->cur;
+  b->xchg[t] = v; b->yield();
+  const unsigned long long r = b->xchg[(t & ~63) | ((t ^ mask) & 63)];
+  b->yield();                      // nobody overwrites its slot before every lane has read
+  return r;
+}
+template <class K> struct CoopArgs { const typename K::Params* p; int bx, by, nbx, threads; unsigned char* lds; };
+template <class K> inline void coop_entry(void* a, int tid) { auto* c = (CoopArgs<K>*)a; K::run(*c->p, c->bx, c->by, c->nbx, tid, c->lds); }
+template <class K>
+inline int launch_coop(Stream*, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
+  static thread_local FiberBlock fb;
+  std::vector<unsigned char> lds(lds_bytes + 16);
+  for (unsigned by = 0; by < gy; by++)
+    for (unsigned bx = 0; bx < gx; bx++) {
+      CoopArgs<K> a{&p, (int)bx, (int)by, (int)gx, threads, lds.data()};
+      fb.run_block(threads, &coop_entry<K>, &a);
+    }
+  return 0;
+}
 MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { if (v < *a) *a = v; }
 MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { if (v > *a) *a = v; }
 MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { unsigned o = *a; *a = o + v; return o; }
@@ -167,6 +222,27 @@ inline int launch(Stream* s, unsigned gx, unsigned gy, int threads, size_t lds_b
   hipLaunchKernelGGL(HIP_KERNEL_NAME(ms_kmain<K>), dim3(gx, gy, 1), dim3(threads, 1, 1), lds_bytes, s, p);
   return (int)hipGetLastError();
 }
+// cooperative style: K::run holds the workgroup barriers itself (per-thread state stays in registers across them)
+template <class K>
+__global__ void __launch_bounds__(K::THREADS, MinWaves<K>::v) ms_kmain_coop(const typename K::Params p) {
+  extern __shared__ __align__(16) unsigned char ms_lds[];
+  K::run(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)threadIdx.x, ms_lds);
+}
+template <class K>
+inline int launch_coop(Stream* s, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
+  if (threads != K::THREADS) return (int)hipErrorInvalidValue;
+  if (lds_bytes > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ms_kmain_coop<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(ms_kmain_coop<K>), dim3(gx, gy, 1), dim3(threads, 1, 1), lds_bytes, s, p);
+  return (int)hipGetLastError();
+}
+// Workgroup barrier of the cooperative kernels, ordering LDS traffic only: __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)), which would end every prefetch (global loads issued for the NEXT tile) at the first barrier behind it.
+// Global data written before the barrier is NOT made visible by it (these kernels never hand global data between waves).
+MS_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+MS_DEV unsigned long long wave_shfl_xor(unsigned long long v, int mask) { return __shfl_xor(v, mask, 64); }
 MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { atomicMin(a, v); }
 MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { atomicMax(a, v); }
 MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { return atomicAdd(a, v); }

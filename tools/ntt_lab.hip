@@ -114,6 +114,102 @@ struct GL3 {
   }
 };
 
+// ---- variant 4: variant 3 with TWO independent operations per asm block (instruction-level parallelism inside one wave:
+// the SGPR round trips of one chain hide behind the other's VALU work), for tiles whose LDS footprint leaves only 2 waves per SIMD
+struct GL4 : GL3 {
+  // (s0, d0) = (a0 + b0, a0 - b0), (s1, d1) = (a1 + b1, a1 - b1); d0 / d1 come in as the wrapped differences
+  static __device__ __forceinline__ void bfly2(u64 a0, u64 b0, u64 a1, u64 b1, u64& s0, u64& d0, u64& s1, u64& d1) {
+    d0 = a0 - b0; d1 = a1 - b1;
+    u64 sv, m0, m1, m2, m3;
+    asm("v_lshl_add_u64 %0, %9, 0, %10\n\t"
+        "v_lshl_add_u64 %1, %11, 0, %12\n\t"
+        "v_cmp_lt_u64 %5, %9, %10\n\t"            // borrow 0
+        "v_cmp_lt_u64 %6, %11, %12\n\t"           // borrow 1
+        "v_cmp_lt_u64 vcc, %0, %9\n\t"            // carry 0
+        "v_cmp_lt_u64 %7, %13, %0\n\t"            // s0 > P-1
+        "v_cmp_lt_u64 %8, %1, %11\n\t"            // carry 1
+        "s_or_b64 %7, %7, vcc\n\t"
+        "v_cmp_lt_u64 vcc, %13, %1\n\t"           // s1 > P-1
+        "s_and_saveexec_b64 %4, %5\n\t"
+        "v_lshl_add_u64 %2, %2, 0, %15\n\t"       // d0 += P
+        "s_and_b64 exec, %4, %6\n\t"
+        "v_lshl_add_u64 %3, %3, 0, %15\n\t"       // d1 += P
+        "s_and_b64 exec, %4, %7\n\t"
+        "s_or_b64 %8, %8, vcc\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %14\n\t"       // s0 += EPS
+        "s_and_b64 exec, %4, %8\n\t"
+        "v_lshl_add_u64 %1, %1, 0, %14\n\t"       // s1 += EPS
+        "s_mov_b64 exec, %4"
+        : "=&v"(s0), "=&v"(s1), "+v"(d0), "+v"(d1), "=&s"(sv), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "s"(GL::P - 1), "s"(GL::EPS), "s"(GL::P) : "vcc", "scc");
+  }
+  // two folds A + h * EPS
+  static __device__ __forceinline__ void fold2(u64& A0, u32 h0, u64& A1, u32 h1) {
+    u64 sv, m0, m1;
+    asm("v_mad_u64_u32 %0, %3, %5, -1, %0\n\t"
+        "v_mad_u64_u32 %1, %4, %6, -1, %1\n\t"
+        "v_cmp_lt_u64 vcc, %7, %0\n\t"
+        "s_or_b64 %3, %3, vcc\n\t"
+        "v_cmp_lt_u64 vcc, %7, %1\n\t"
+        "s_and_saveexec_b64 %2, %3\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %8\n\t"
+        "s_or_b64 %4, %4, vcc\n\t"
+        "s_and_b64 exec, %2, %4\n\t"
+        "v_lshl_add_u64 %1, %1, 0, %8\n\t"
+        "s_mov_b64 exec, %2"
+        : "+v"(A0), "+v"(A1), "=&s"(sv), "=&s"(m0), "=&s"(m1) : "v"(h0), "v"(h1), "s"(GL::P - 1), "s"(GL::EPS) : "vcc", "scc");
+  }
+};
+// shift-multiply pre-steps shared by the paired path: x * 2^S = fold-chain; stage k of value v: returns (A, h) of the next fold, or applies x64
+template <int S> struct ShiftPlan {
+  static constexpr int T = S % 32, Q = S / 32;   // 2^S = 2^T * (2^32)^Q
+};
+template <int S0, int S1> __device__ __forceinline__ void mul_pow2_pair(u64& x0, u64& x1) {
+  // both go through the same kind of steps only when their (T != 0, Q) classes agree; otherwise fall back to the unpaired chain
+  constexpr int T0 = S0 % 32, Q0 = S0 / 32, T1 = S1 % 32, Q1 = S1 / 32;
+  if constexpr ((T0 != 0) && (T1 != 0)) {
+    u64 A0 = x0 << T0, A1 = x1 << T1;
+    GL4::fold2(A0, GL::hi(x0) >> (32 - T0), A1, GL::hi(x1) >> (32 - T1));
+    x0 = A0; x1 = A1;
+  } else { x0 = GL3::mul_pow2<T0>(x0); x1 = GL3::mul_pow2<T1>(x1); }
+  if constexpr (Q0 >= 1 && Q1 >= 1 && Q0 == 1 && Q1 == 1) {
+    u64 A0 = x0 << 32, A1 = x1 << 32;
+    GL4::fold2(A0, GL::hi(x0), A1, GL::hi(x1));
+    x0 = A0; x1 = A1;
+  } else {
+    if constexpr (Q0 == 1) x0 = GL3::mul_x32(x0); else if constexpr (Q0 == 2) x0 = GL3::mul_x64(x0);
+    if constexpr (Q1 == 1) x1 = GL3::mul_x32(x1); else if constexpr (Q1 == 2) x1 = GL3::mul_x64(x1);
+  }
+}
+template <int LOG2H2, int J> struct TwExp { static constexpr int E = (39 * (64 >> LOG2H2) * J) % 192; static constexpr bool NEG = E >= 96; static constexpr int S = NEG ? E - 96 : E; };
+// paired radix-2^B DIF: butterflies two at a time
+template <int B, int S, int BLK, int J> struct Stage2 {
+  static __device__ __forceinline__ void run(u64 (&x)[1 << B]) {
+    constexpr int h = 1 << S;
+    if constexpr (h >= 2) {
+      const u64 a0 = x[BLK + J], b0 = x[BLK + J + h], a1 = x[BLK + J + 1], b1 = x[BLK + J + 1 + h];
+      typedef TwExp<S + 1, J> E0; typedef TwExp<S + 1, J + 1> E1;
+      u64 s0, d0, s1, d1;
+      // a negative twiddle multiplies (b - a): swap the operands of that difference
+      if constexpr (!E0::NEG && !E1::NEG) GL4::bfly2(a0, b0, a1, b1, s0, d0, s1, d1);
+      else {  // rare enough: unpaired differences, paired sums via the general block with swapped roles is not possible -> plain ops
+        s0 = GL3::add(a0, b0); s1 = GL3::add(a1, b1);
+        d0 = E0::NEG ? GL3::sub(b0, a0) : GL3::sub(a0, b0); d1 = E1::NEG ? GL3::sub(b1, a1) : GL3::sub(a1, b1);
+      }
+      mul_pow2_pair<(J == 0 ? 0 : E0::S), E1::S>(d0, d1);
+      x[BLK + J] = s0; x[BLK + J + h] = d0; x[BLK + J + 1] = s1; x[BLK + J + 1 + h] = d1;
+      if constexpr (J + 2 < h) Stage2<B, S, BLK, J + 2>::run(x);
+      else if constexpr (BLK + 2 * h < (1 << B)) Stage2<B, S, BLK + 2 * h, 0>::run(x);
+      else Stage2<B, S - 1, 0, 0>::run(x);
+    } else {  // last stage: blocks of 2, paired two blocks at a time
+      u64 s0, d0, s1, d1;
+      GL4::bfly2(x[BLK], x[BLK + 1], x[BLK + 2], x[BLK + 3], s0, d0, s1, d1);
+      x[BLK] = s0; x[BLK + 1] = d0; x[BLK + 2] = s1; x[BLK + 3] = d1;
+      if constexpr (BLK + 4 < (1 << B)) Stage2<B, S, BLK + 4, 0>::run(x);
+    }
+  }
+};
+
 template <class A, int LOG2H2, int J> __device__ __forceinline__ u64 tw(u64 a, u64 b) {
   constexpr int EXP = (39 * (64 >> LOG2H2) * J) % 192;
   if constexpr (EXP >= 96) return A::template mul_pow2<EXP - 96>(A::sub(b, a));
@@ -135,6 +231,7 @@ template <class A, int B, int MODE> __global__ void __launch_bounds__(256) lab(u
   const int tid = blockIdx.x * 256 + threadIdx.x;
   for (int i = 0; i < (1 << B); i++) x[i] = in[(tid * 7 + i * 13) & 4095];
   for (int it = 0; it < iters; it++) {
+    if constexpr (MODE == 4) Stage2<B, B - 1, 0, 0>::run(x);                               // paired masked-asm radix-2^B DIF
     if (MODE == 0) Stage<A, B, B - 1, 0, 0>::run(x);                                      // full radix-2^B DIF (adds, subs, shift twiddles)
     if (MODE == 1) { for (int i = 0; i < (1 << B); i += 2) { u64 a = x[i], b = x[i + 1]; x[i] = A::add(a, b); x[i + 1] = A::sub(a, b); } }  // add/sub only
     if (MODE == 2) { _Pragma("unroll") for (int i = 0; i < (1 << B); i++) x[i] = GLT::mul(x[i], x[(i + 1) & ((1 << B) - 1)]); }              // general multiplies
@@ -196,7 +293,28 @@ template <class A> int check(const char* name) {
   hipFree(d_in); hipFree(d_out);
   return bad;
 }
+__global__ void check_pair_k(u64* out, const u64* in) {
+  u64 x[32], y[32];
+  for (int i = 0; i < 32; i++) x[i] = y[i] = in[(threadIdx.x * 32 + i) & 65535];
+  Stage<GL1, 5, 4, 0, 0>::run(x);
+  Stage2<5, 4, 0, 0>::run(y);
+  u64 bad = 0;
+  for (int i = 0; i < 32; i++) bad |= (x[i] ^ y[i]);
+  out[threadIdx.x] = bad;
+}
 int main() {
+  {
+    std::vector<u64> h(65536); u64 s = 12345;
+    for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = s % GL::P; }
+    for (int i = 0; i < 65536; i += 7) h[i] = (i % 3) ? GL::P - 1 - (i % 5) : (u64)(i % 4);
+    u64 *di, *dout; hipMalloc(&di, 65536 * 8); hipMalloc(&dout, 256 * 8);
+    hipMemcpy(di, h.data(), 65536 * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(check_pair_k, dim3(1), dim3(256), 0, 0, dout, di);
+    u64 r[256]; hipMemcpy(r, dout, sizeof r, hipMemcpyDeviceToHost);
+    u64 bad = 0; for (int i = 0; i < 256; i++) bad |= r[i];
+    printf("check paired radix-32 network == sign-bit network: %s\n", bad ? "FAILED" : "ok");
+  }
+
   check<GLr>("r02 sign-bit GLT (field.hpp)");
   check<GL3>("masked asm");
 
@@ -213,6 +331,8 @@ int main() {
     run<GL1, 5, 0>("r02 radix-32 DIF", d_out, d_in, blocks, 32 * 5);
     run<GL3, 5, 0>("masked-asm radix-32 DIF", d_out, d_in, blocks, 32 * 5);
     run<GL3, 4, 0>("masked-asm radix-16 DIF", d_out, d_in, blocks, 16 * 4);
+    run<GL4, 5, 4>("paired masked-asm radix-32 DIF", d_out, d_in, blocks, 32 * 5);
+    run<GL4, 4, 4>("paired masked-asm radix-16 DIF", d_out, d_in, blocks, 16 * 4);
     run<GL3, 4, 3>("masked-asm general multiply (16 values)", d_out, d_in, blocks, 16);
   }
   g_lds = 0;
