@@ -14,6 +14,7 @@
 // commitments between the transcript and the stage functions and calls nothing but ms_* symbols, which are resolved at
 // load time from the already-loaded libministark.so.  verify() is host arithmetic (csrc/field.hpp), like the reference's.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -98,12 +99,19 @@ struct TraceTable {
 
 // byte buffer in page-locked host memory (ms_pinned_alloc: hipHostMalloc): the device copies the ~64 MiB FRI proof into it by DMA
 struct PinnedBuf {
-  u8* p = nullptr; size_t n = 0, cap = 0;
+  u8* p = nullptr; size_t n = 0, cap = 0; bool pinned = false;   // plain malloc when page-locking is not available (no GPU in the process)
+  void drop() { if (p) { if (pinned) ms_pinned_free(p); else free(p); } p = nullptr; cap = 0; }
   PinnedBuf() {}
   PinnedBuf(const PinnedBuf& o) { assign(o.p, o.p + o.n); }
   PinnedBuf& operator=(const PinnedBuf& o) { if (this != &o) assign(o.p, o.p + o.n); return *this; }
-  ~PinnedBuf() { if (p) ms_pinned_free(p); }
-  void reserve(size_t m) { if (m <= cap) return; if (p) ms_pinned_free(p); p = (u8*)ms_pinned_alloc(m); cap = p ? m : 0; }
+  ~PinnedBuf() { drop(); }
+  void reserve(size_t m) {
+    if (m <= cap) return;
+    drop();
+    p = (u8*)ms_pinned_alloc(m); pinned = p != nullptr;
+    if (!p) p = (u8*)malloc(m);
+    cap = p ? m : 0;
+  }
   void assign(size_t m, u8 v) { reserve(m); n = p ? m : 0; if (n) memset(p, v, n); }
   void resize_uninit(size_t m) { reserve(m); n = p ? m : 0; }
   void assign(const u8* a, const u8* b) { const size_t m = (size_t)(b - a); reserve(m); n = p ? m : 0; if (n) memcpy(p, a, n); }
