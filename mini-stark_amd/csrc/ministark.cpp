@@ -267,7 +267,7 @@ template <class F> struct Ctx : CtxBase {
       const int sub = kv.first; char name[160], buf[320];
       const char* fld = F::ID == 0 ? "GL" : "BB";
       if (sub & 128) snprintf(name, sizeof name, "msntt::PassKernel2<%s, %s, %s, %d, %d, %d, %d, %d>", fld, (sub & 2048) ? "GLM" : (F::ID == 0 ? "GLT" : "BB"), (sub & 64) ? "true" : "false",
-                              sub & 15, (sub >> 8) & 7, (sub & 2048) ? (((sub >> 8) & 7) == 4 ? 1024 : 512) : 256, (sub & 2048) ? 3 : 2, (sub >> 12) & 3);
+                              sub & 15, (sub >> 8) & 7, (sub & 2048) ? (((sub >> 8) & 7) == 4 ? 1024 : ((sub & 15) == 8 ? 256 : 512)) : 256, (sub & 2048) ? 3 : 2, (sub >> 12) & 3);
       else if (sub & 32) snprintf(name, sizeof name, "msntt::PassKernel<%s, %s, %d>", fld, (sub & 64) ? "true" : "false", (sub & 16) ? 512 : 256);
       else snprintf(name, sizeof name, "msntt::PassKernelK<%s, %s, %d, %d>", fld, (sub & 64) ? "true" : "false", sub & 15, (sub & 16) ? 512 : 256);
       snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"alg_bytes\": %.0f}", first ? "" : ", ", name, sub_cnt[sub], kv.second, sub_by[sub]);
@@ -409,6 +409,15 @@ template <class F> struct Ctx : CtxBase {
       next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | 2048 | (MODE << 12);
       return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch) > 256 ? 256 : coop_grid(tiles * batch), 1024, KK::lds_bytes(), pp);
     }
+    if constexpr (F::ID == 0 && (K == 8 || K == 9) && LC == 3) {
+      if (ntt_v2_sub3) {   // smaller tiles of the three-pass plans: 8 elements per thread, radix 8 x 8 x 4 (or 8), many workgroups per CU
+        constexpr int TH3 = (K == 8) ? 256 : 512;
+        typedef msntt::PassKernel2<F, GLM, INV, K, LC, TH3, 3, MODE> KK;
+        if (!KK::applicable(pp)) return 998;
+        next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | 2048 | (MODE << 12);
+        return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch, K == 8 ? 8 : 4), TH3, KK::lds_bytes(), pp);
+      }
+    }
     if constexpr (F::ID == 0 && K == 10 && LC == 3) {
       if (ntt_v2_sub3) {   // 512 threads, three sub-rounds, exec-masked arithmetic: 16 waves per CU
         typedef msntt::PassKernel2<F, GLM, INV, K, LC, 512, 3, MODE> KK;
@@ -424,7 +433,7 @@ template <class F> struct Ctx : CtxBase {
   }
   // persistent grid of the cooperative pass kernels: two workgroups per CU (their 72-80 KiB of LDS), a multiple of 8 (XCD-aware tile walk)
   int ntt_coop_wgs = 512;
-  unsigned coop_grid(size_t work_items) const { return (unsigned)(work_items < (size_t)ntt_coop_wgs ? work_items : (size_t)ntt_coop_wgs); }
+  unsigned coop_grid(size_t work_items, int per_cu = 2) const { const size_t g = (size_t)ntt_coop_wgs * per_cu / 2; return (unsigned)(work_items < g ? work_items : g); }
   template <bool INV, int K, int LC>
   int launch_v2(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
     if (pp.log_r0) { if constexpr (LC == 3) return launch_v2m<INV, K, LC, 2>(pp, tiles, batch); else return 996; }
@@ -946,7 +955,7 @@ template <class F> struct Ctx : CtxBase {
     XE sq = z;
     for (int i = 0; i < 9; i++) { p.zpow2[i] = sq; sq = e_mul<F>(sq, sq); }
     p.partials = nblocks > 1 ? d_partials.as<T>() : dst;  // single block: P_0 is the value
-    CK(run<EK>(K_EVAL, (unsigned)nblocks, 1, EK::THREADS, EK::lds_bytes(), p));
+    CK(run_coop<EK>(K_EVAL, (unsigned)nblocks, EK::THREADS, EK::lds_bytes(), p));
     if (nblocks > 1) {
       typedef mspoly::ReducePartialsKernel<F, E> RK;
       typename RK::Params rp;
@@ -956,7 +965,7 @@ template <class F> struct Ctx : CtxBase {
       rp.zc = zc;
       XE zs = e_pow<F, E>(zc, rp.per_thread);
       for (int i = 0; i < 8; i++) { rp.zs2[i] = zs; zs = e_mul<F>(zs, zs); }
-      CK(run<RK>(K_EVAL_REDUCE, 1, 1, RK::THREADS, RK::lds_bytes(), rp));
+      CK(run_coop<RK>(K_EVAL_REDUCE, 1, RK::THREADS, RK::lds_bytes(), rp));
     }
     return 0;
   }

@@ -456,8 +456,9 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
 //   log_r0 == LC (GL: 3)       first pass behind the virtual zero-padding pass: the C columns of a tile are the r0 cosets of ONE
 //                              coefficient index, the tile's output is one contiguous block of r0 * r elements
 template <int K, int NSUB> struct Digits2 {
-  // digit sizes, top digit first: NSUB == 2: (ceil(K/2), floor(K/2)); NSUB == 3: (K - 2*(K/3), K/3, K/3)
-  static constexpr int bits(int s) { return NSUB == 2 ? (s == 0 ? (K + 1) / 2 : K / 2) : (s == 0 ? K - 2 * (K / 3) : K / 3); }
+  // digit sizes, top digit first: NSUB == 2: (ceil(K/2), floor(K/2)); NSUB == 3: last = K/3, middle = (K - last)/2, top = the rest
+  // (10: 4,3,3   9: 3,3,3   8: 3,3,2   7: 3,2,2)
+  static constexpr int bits(int s) { return NSUB == 2 ? (s == 0 ? (K + 1) / 2 : K / 2) : (s == 2 ? K / 3 : (s == 1 ? (K - K / 3) / 2 : K - K / 3 - (K - K / 3) / 2)); }
   static constexpr int slo(int s) { int d = 0; for (int t = 0; t <= s; t++) d += bits(t); return K - d; }
 };
 // MODE (compile time, so that each instance carries one load and one store path): 0 first pass of a plain transform,
@@ -602,6 +603,15 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       const size_t f0 = tl << LC;
       const bool row_tw = MODE != 0 && !p.last && (f0 >> p.log_Rp) != 0;
       // ---- the prefetched inputs go to LDS (behind the virtual pass: times w_(r0 r)^(i1 * row)); the row twiddles of this tile
+#ifdef MS_ABL_COPYONLY   // ablation: the pass's global access pattern alone (rows in, rows out), no LDS, no barriers, no arithmetic
+      if constexpr (MODE == 1) {
+        const size_t k_low_ = f0 >> p.log_Rp, i_done_ = (f0 & (((size_t)1 << p.log_Rp) - 1)) + c0;
+        T* out_ = p.dst + by * p.dst_bstride + ((k_low_ << p.log_Rp) << K) + i_done_;
+#pragma unroll
+        for (int i = 0; i < SWEEPS; i++) *reinterpret_cast<V16*>(out_ + ((size_t)row_to_inew(rb + i * RPS) << p.log_Rp)) = rows[i];
+        continue;
+      }
+#endif
       if (row_tw) {
         const size_t k_low = f0 >> p.log_Rp;
         for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);   // w_n^(k_low * Rp * i_new)

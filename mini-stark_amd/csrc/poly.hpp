@@ -124,50 +124,58 @@ template <class F, int EC, int E> struct EvalKernel {
     Ext<F, E> zpow2[9];   // z^(2^i), i <= 8  (zpow2[8] = z^THREADS)
     T* partials;          // [nblocks][npoly][E]
   };
-  static MS_HD int nphases(const Params&) { return 2; }
-  static MS_HD size_t lds_bytes() { return (size_t)MAX_POLYS * E * THREADS * sizeof(T); }
+  static MS_HD size_t lds_bytes() { return (size_t)MAX_POLYS * E * (THREADS / 64) * sizeof(T); }
   static MS_DEV Ext<F, E> mul_coef(const Ext<F, E>& pw, const T* c) {
     if (EC == 1) return e_mul_base<F, E>(pw, c[0]);
     Ext<F, E> cc; for (int l = 0; l < E; l++) cc.c[l] = c[l < EC ? l : 0];
     return e_mul<F>(pw, cc);
   }
-  static MS_DEV void phase(int ph, const Params& p, int bx, int, int tid, int nthreads, unsigned char* lds) {
-    T* red = reinterpret_cast<T*>(lds);  // [npoly*E][THREADS]
-    if (ph == 0) {
-      Ext<F, E> acc[MAX_POLYS];
-      for (int i = 0; i < MAX_POLYS; i++) acc[i] = e_zero<F, E>();
-      size_t k = (size_t)bx * (THREADS * ITEMS) + tid;
-      size_t kmax = 0;
-      for (int i = 0; i < MAX_POLYS; i++) if (i < p.npoly && p.count[i] > kmax) kmax = p.count[i];
-      if (k < kmax) {
-        Ext<F, E> pw = e_one<F, E>();
+  // Cooperative kernel (barrier inside): the block sum runs as a butterfly of wave shuffles (6 steps) plus one LDS hop between the
+  // four waves, instead of `width` threads each adding 256 LDS values one after the other (a ~3 us dependent chain per launch, and
+  // these launches sit on the proof's latency path: 2 per FRI round).
+  static MS_DEV void run(const Params& p, int bx, int, int, int tid, unsigned char* lds) {
+    T* red = reinterpret_cast<T*>(lds);  // [npoly*E][waves]
+    constexpr int WAVES = THREADS / 64;
+    Ext<F, E> acc[MAX_POLYS];
+    for (int i = 0; i < MAX_POLYS; i++) acc[i] = e_zero<F, E>();
+    size_t k = (size_t)bx * (THREADS * ITEMS) + tid;
+    size_t kmax = 0;
+    for (int i = 0; i < MAX_POLYS; i++) if (i < p.npoly && p.count[i] > kmax) kmax = p.count[i];
+    if (k < kmax) {
+      Ext<F, E> pw = e_one<F, E>();
 #pragma unroll
-        for (int i = 0; i < 8; i++) if ((tid >> i) & 1) pw = e_mul<F>(pw, p.zpow2[i]);
-        const Ext<F, E> zstep = p.zpow2[8];
-        for (int it = 0; it < ITEMS && k < kmax; it++, k += THREADS) {
+      for (int i = 0; i < 8; i++) if ((tid >> i) & 1) pw = e_mul<F>(pw, p.zpow2[i]);
+      const Ext<F, E> zstep = p.zpow2[8];
+      for (int it = 0; it < ITEMS && k < kmax; it++, k += THREADS) {
 #pragma unroll
-          for (int i = 0; i < MAX_POLYS; i++) {
-            if (i < p.npoly && k < p.count[i]) {
-              T c[EC];
-              const T* ptr = p.base + (size_t)i * p.poly_stride + p.off[i] + k * p.kstride;
-              for (int l = 0; l < EC; l++) c[l] = ptr[(size_t)l * p.limb_stride];
-              acc[i] = e_add<F, E>(acc[i], mul_coef(pw, c));
-            }
+        for (int i = 0; i < MAX_POLYS; i++) {
+          if (i < p.npoly && k < p.count[i]) {
+            T c[EC];
+            const T* ptr = p.base + (size_t)i * p.poly_stride + p.off[i] + k * p.kstride;
+            for (int l = 0; l < EC; l++) c[l] = ptr[(size_t)l * p.limb_stride];
+            acc[i] = e_add<F, E>(acc[i], mul_coef(pw, c));
           }
-          pw = e_mul<F>(pw, zstep);
+        }
+        pw = e_mul<F>(pw, zstep);
+      }
+    }
+    const int width = p.npoly * E;
+#pragma unroll
+    for (int i = 0; i < MAX_POLYS; i++) {
+      if (i < p.npoly) {
+#pragma unroll
+        for (int l = 0; l < E; l++) {
+          T v = acc[i].c[l];
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) v = F::add(v, (T)msrt::wave_shfl_xor((unsigned long long)v, m));
+          if ((tid & 63) == 0) red[(size_t)(i * E + l) * WAVES + (tid >> 6)] = v;
         }
       }
-#pragma unroll
-      for (int i = 0; i < MAX_POLYS; i++)
-        if (i < p.npoly)
-          for (int l = 0; l < E; l++) red[(size_t)(i * E + l) * nthreads + tid] = acc[i].c[l];
-      return;
     }
-    // block sum: 4 lanes per output, then one lane adds the 4
-    const int width = p.npoly * E;
+    msrt::wg_barrier();
     if (tid < width) {
       T s = 0;
-      for (int t = 0; t < nthreads; t++) s = F::add(s, red[(size_t)tid * nthreads + t]);
+      for (int t = 0; t < WAVES; t++) s = F::add(s, red[(size_t)tid * WAVES + t]);
       p.partials[(size_t)bx * width + tid] = s;
     }
   }
@@ -179,41 +187,47 @@ template <class F, int E> struct ReducePartialsKernel {
   typedef typename F::T T;
   static constexpr int THREADS = mspoly::THREADS;
   struct Params { const T* partials; size_t nblocks, per_thread /* S */; int npoly; Ext<F, E> zc; Ext<F, E> zs2[8]; T* out; };
-  static MS_HD int nphases(const Params&) { return 2; }
-  static MS_HD size_t lds_bytes() { return (size_t)MAX_POLYS * E * THREADS * sizeof(T); }
-  static MS_DEV void phase(int ph, const Params& p, int, int, int tid, int nthreads, unsigned char* lds) {
+  static MS_HD size_t lds_bytes() { return (size_t)MAX_POLYS * E * (THREADS / 64) * sizeof(T); }
+  static MS_DEV void run(const Params& p, int, int, int, int tid, unsigned char* lds) {   // cooperative: wave-shuffle block sum, as EvalKernel
     T* red = reinterpret_cast<T*>(lds);
+    constexpr int WAVES = THREADS / 64;
     const int width = p.npoly * E;
-    if (ph == 0) {
-      const size_t b0 = (size_t)tid * p.per_thread;
-      Ext<F, E> acc[MAX_POLYS];
-      for (int i = 0; i < MAX_POLYS; i++) acc[i] = e_zero<F, E>();
-      if (b0 < p.nblocks) {
-        size_t b1 = b0 + p.per_thread; if (b1 > p.nblocks) b1 = p.nblocks;
-        for (size_t b = b1; b-- > b0;) {
+    const size_t b0 = (size_t)tid * p.per_thread;
+    Ext<F, E> acc[MAX_POLYS];
+    for (int i = 0; i < MAX_POLYS; i++) acc[i] = e_zero<F, E>();
+    if (b0 < p.nblocks) {
+      size_t b1 = b0 + p.per_thread; if (b1 > p.nblocks) b1 = p.nblocks;
+      for (size_t b = b1; b-- > b0;) {
 #pragma unroll
-          for (int i = 0; i < MAX_POLYS; i++) {
-            if (i < p.npoly) {
-              Ext<F, E> v; for (int l = 0; l < E; l++) v.c[l] = p.partials[b * width + i * E + l];
-              acc[i] = e_add<F, E>(e_mul<F>(acc[i], p.zc), v);
-            }
+        for (int i = 0; i < MAX_POLYS; i++) {
+          if (i < p.npoly) {
+            Ext<F, E> v; for (int l = 0; l < E; l++) v.c[l] = p.partials[b * width + i * E + l];
+            acc[i] = e_add<F, E>(e_mul<F>(acc[i], p.zc), v);
           }
         }
-        Ext<F, E> sc = e_one<F, E>();
-#pragma unroll
-        for (int i = 0; i < 8; i++) if ((tid >> i) & 1) sc = e_mul<F>(sc, p.zs2[i]);
-#pragma unroll
-        for (int i = 0; i < MAX_POLYS; i++) if (i < p.npoly) acc[i] = e_mul<F>(acc[i], sc);
       }
+      Ext<F, E> sc = e_one<F, E>();
 #pragma unroll
-      for (int i = 0; i < MAX_POLYS; i++)
-        if (i < p.npoly)
-          for (int l = 0; l < E; l++) red[(size_t)(i * E + l) * nthreads + tid] = acc[i].c[l];
-      return;
+      for (int i = 0; i < 8; i++) if ((tid >> i) & 1) sc = e_mul<F>(sc, p.zs2[i]);
+#pragma unroll
+      for (int i = 0; i < MAX_POLYS; i++) if (i < p.npoly) acc[i] = e_mul<F>(acc[i], sc);
     }
+#pragma unroll
+    for (int i = 0; i < MAX_POLYS; i++) {
+      if (i < p.npoly) {
+#pragma unroll
+        for (int l = 0; l < E; l++) {
+          T v = acc[i].c[l];
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) v = F::add(v, (T)msrt::wave_shfl_xor((unsigned long long)v, m));
+          if ((tid & 63) == 0) red[(size_t)(i * E + l) * WAVES + (tid >> 6)] = v;
+        }
+      }
+    }
+    msrt::wg_barrier();
     if (tid < width) {
       T s = 0;
-      for (int t = 0; t < nthreads; t++) s = F::add(s, red[(size_t)tid * nthreads + t]);
+      for (int t = 0; t < WAVES; t++) s = F::add(s, red[(size_t)tid * WAVES + t]);
       p.out[tid] = s;
     }
   }

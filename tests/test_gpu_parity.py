@@ -366,3 +366,12 @@ def test_mssp_roundtrip_across_processes(mk, field, log_n, tmp_path):
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, os.path.join(here, "verify_worker.py"), str(f), str(field), str(steps), "8"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "VERIFY accepted tampered-rejected" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("field,log_rows", [(0, 12), (1, 10), (0, 16)])
+def test_c_caller_on_gpu(field, log_rows, tmp_path):
+    """SURVEY 8(f) rank 4 stand-in: examples/prove_c_caller.c, a compiled C program linked against libministark.so (HIP) and
+    libministark_host.so, runs the reference's e2e flow (derive_constrains, prove, serialise, verify, tamper) on the GPU."""
+    import test_c_caller as tcc
+    out = tcc.build_and_run(os.path.dirname(ms.library_path()), "ministark", [field, log_rows, 8], tmp_path)
+    assert out.returncode == 0 and "verify accepted, tampered rejected" in out.stdout, (out.stdout, out.stderr)
