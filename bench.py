@@ -259,22 +259,30 @@ def main():
         kname, k = max(variants.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = k["ms"] / max(1, k["launches"])
         achieved = (k["alg_bytes"] / max(1, k["launches"])) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc_variants = None, None, {}
         for name in ("r02_pmc_ntt_pass.json", "pmc_ntt_pass.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
                     pj = json.load(open(pmc))
+                    pmc_variants = pj.get("variants", {})
                     if pj.get("kernel") == kname:
                         traffic, traffic_src = pj.get("hbm_bytes_per_launch"), "profiles/" + name
                         break
                 except Exception:
                     pass
+        per_variant = {}
+        for vn, v in variants.items():   # every NTT pass template instance of the proof: live time, algorithmic rate, PMC traffic (constant from the profile) on the live time
+            a_ms = v["ms"] / max(1, v["launches"])
+            tb = pmc_variants.get(vn, {}).get("hbm_bytes_per_launch")
+            per_variant[vn] = {"launches_per_proof": v["launches"], "avg_launch_ms": a_ms, "alg_GBps": (v["alg_bytes"] / max(1, v["launches"])) / (a_ms * 1e-3) / 1e9 if a_ms else 0.0,
+                               "traffic_bytes_per_launch": tb, "frac_of_hbm_peak_on_traffic": (tb / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb and a_ms else None}
         allp = prof["ntt_pass"]
         out["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round, gfx950 corrections applied; a constant, not measured in this run)") if traffic_src else None,
                            "frac_on_traffic": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
                            "launches_per_proof": k["launches"], "avg_launch_ms": avg_ms, "alg_bytes_per_launch": k["alg_bytes"] / max(1, k["launches"]),
+                           "variants": per_variant,
                            "all_ntt_pass_kernels": {"launches_per_proof": allp["launches"], "ms_per_proof": allp["ms"],
                                                     "alg_GBps": allp["alg_bytes"] / (allp["ms"] * 1e-3) / 1e9 if allp["ms"] else 0.0},
                            "note": "pass kernels are bound by the NUMBER of VALU instructions (3.3-3.6 issue cycles each in integer code, tools/ntt_lab.hip), not by HBM (DESIGN.md 6.2)"}
