@@ -544,6 +544,9 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #ifndef MS_NTT_PREFETCH
 #define MS_NTT_PREFETCH 0
 #endif
+#ifndef MS_NTT_VLOAD_UNROLL
+#define MS_NTT_VLOAD_UNROLL 4   // coefficient + twiddle gathers in flight per thread in the load of the pass behind the virtual pass
+#endif
   static constexpr bool PREFETCH = MS_NTT_PREFETCH != 0;
   static constexpr int NROWS = (MODE == 2) ? 1 : SWEEPS, NXS = (MODE == 2) ? (R * C / TH) : 1;   // prefetch registers: whole 16-byte row pieces or, behind the virtual pass, single coefficients
   static MS_DEV void locate(size_t g, size_t tiles, size_t* tile, size_t* by) { *by = g / tiles; *tile = g - *by * tiles; }
@@ -633,7 +636,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         } else {
           const size_t n = (size_t)1 << p.log_n, k2 = f0 >> LC, nprime = n >> (LC + K);
           const T* src = p.src + by * p.src_bstride;
-#pragma unroll 4
+#pragma unroll MS_NTT_VLOAD_UNROLL
           for (int idx = tid; idx < R * C; idx += TH) {
             const int row = idx >> LC, i1 = idx & (C - 1);
             const size_t k = k2 + nprime * (size_t)row;
