@@ -12,7 +12,8 @@ def mk(field, fresh=False):
 for field in (0, 1):
     for log_n in (0, 1, 3, 5, 9, 10, 11, 12, 13, 14):
         pc.case_ntt(mk, field, log_n)
-    pc.case_coset_lde(mk, field, 4, 8); pc.case_coset_lde(mk, field, 9, 4)
+    pc.case_coset_lde(mk, field, 4, 8); pc.case_coset_lde(mk, field, 9, 4); pc.case_coset_lde(mk, field, 14, 8)   # the last one: cooperative tiles behind the virtual pass
+    if field == 0: pc.case_ntt(mk, field, 19, batch=1)   # 2^10-row cooperative tile (fibers), exec-masked class's host formulas
     for a in [(16, 1, 2, 2), (16, 1, 4, 4), (3, 1, 2, 2), (4096, 1, 2, 2), (6144, 1, 6, 2), (64, pc.EXT[field], 2, 2), (1 << 13, pc.EXT[field], 2, 2)]:
         pc.case_merkle(mk, field, *a, special=True)
     for lpn, ext in ((6, 1), (16, 1), (2, pc.EXT[field])):
