@@ -115,7 +115,10 @@ class HostStark:
     def verify(self, constrains, proof: StarkProof, zero_display_empty=True) -> bool:
         """Stark::verify (src/starks.rs:171-235, with Fri::verify src/fri.rs:191-290 and MerkleRoot::check_proof
         src/merkle.rs:312-338) on the CPU, as in the reference.  Returns True/False; the reason of a rejection is in
-        `self.last_verify_error`.  Raises MsError on malformed input."""
+        `self.last_verify_error`.  Raises MsError on malformed input.
+        A PARITY MIRROR of the reference's verifier, NOT a sound verifier: like the reference it takes round 0's root from the proof
+        (it never enters the transcript), does not tie y3 of a window to the next window, does not check the last round polynomial
+        and only degree-bounds the shipped quotients.  True means "the reference would accept" (INTEGRATION.md section 8)."""
         cs = np.ascontiguousarray(constrains, dtype=np.uint64)
         c, N = cs.shape
         ev = np.ascontiguousarray(np.concatenate([np.asarray(proof.constrain_queries, dtype=np.uint64).reshape(-1, c, self.ctx.e),

@@ -152,3 +152,12 @@ def test_lincomb_many_terms(mk, field, k, linear):
 @pytest.mark.parametrize("field", [0, 1])
 def test_device_trace_range_check(mk, field):
     pc.case_device_trace_range_check(mk, field, lambda a: (a.ctypes.data, a))   # emulation: "device" memory is host memory
+
+
+def test_babybear_on_the_round2_tiles(mk, monkeypatch):
+    """BabyBear runs the round-1 NTT tiles by default (they measured faster); MS_NTT_V2=2 puts it on the cooperative round-2 tiles,
+    which must stay exact."""
+    monkeypatch.setenv("MS_NTT_V2", "2")
+    fresh = lambda f, fresh=False: mk(f, fresh=True)
+    pc.case_ntt(fresh, 1, 16)
+    pc.case_coset_lde(fresh, 1, 14, 8)

@@ -375,3 +375,12 @@ def test_c_caller_on_gpu(field, log_rows, tmp_path):
     import test_c_caller as tcc
     out = tcc.build_and_run(os.path.dirname(ms.library_path()), "ministark", [field, log_rows, 8], tmp_path)
     assert out.returncode == 0 and "verify accepted, tampered rejected" in out.stdout, (out.stdout, out.stderr)
+
+
+def test_babybear_on_the_round2_tiles(mk, monkeypatch):
+    """BabyBear runs the round-1 NTT tiles by default (they measured faster); MS_NTT_V2=2 puts it on the cooperative round-2 tiles,
+    which must stay exact."""
+    monkeypatch.setenv("MS_NTT_V2", "2")
+    fresh = lambda f, fresh=False: mk(f, fresh=True)
+    pc.case_ntt(fresh, 1, 16)
+    pc.case_coset_lde(fresh, 1, 14, 8)
