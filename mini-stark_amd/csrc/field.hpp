@@ -195,7 +195,8 @@ struct GLM : GL {
         : "=&v"(T0), "=&v"(M), "=&v"(T1), "=&s"(c) : "v"(lo(a)), "v"(hi(a)), "v"(lo(b)), "v"(hi(b)) : "vcc");
     // 128-bit (lo, hi) = T0 + M * 2^32 + T1 * 2^64 + c * 2^96;  r = lo - hi_hi, then + hi_lo * EPS
     u32 L1, H0, H1, R0, R1; u64 bm;
-    asm("v_addc_co_u32 %2, vcc, %9, 0, %11\n\t"   // H1 = hi(T1) + c   (no wrap: the product is < 2^128)
+    asm("s_nop 1\n\t"                               // c was written by the VALU instruction that ended the previous statement
+        "v_addc_co_u32 %2, vcc, %9, 0, %11\n\t"   // H1 = hi(T1) + c   (no wrap: the product is < 2^128)
         "v_add_co_u32 %0, vcc, %6, %7\n\t"        // L1 = hi(T0) + lo(M)
         "s_nop 1\n\t"
         "v_addc_co_u32 %1, vcc, %10, %8, vcc\n\t" // H0 = lo(T1) + hi(M) + carry

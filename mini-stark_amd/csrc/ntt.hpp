@@ -564,6 +564,12 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #else
         for (int i = 0; i < SWEEPS; i++) rows[i] = *reinterpret_cast<const V16*>(s0 + (size_t)(i * RPS) * cs);
 #endif
+#ifdef MS_ABL_CONTIGREAD   // ablation (timing only, wrong values): the tile read as ONE contiguous 64 KiB block instead of 1024 pieces 64 KiB apart
+        if constexpr (MODE == 1) {
+          const T* t0 = src + (f0 << K) + (size_t)(rb * C + c0);
+          for (int i = 0; i < SWEEPS; i++) rows[i] = *reinterpret_cast<const V16*>(t0 + (size_t)(i * RPS) * C);
+        }
+#endif
       } else {
 #pragma unroll
         for (int i = 0; i < SWEEPS; i++) {

@@ -241,7 +241,11 @@ inline int launch_coop(Stream* s, unsigned gx, unsigned gy, int threads, size_t 
 // Workgroup barrier of the cooperative kernels, ordering LDS traffic only: __syncthreads() also drains the vector-memory counter
 // (s_waitcnt vmcnt(0)), which would end every prefetch (global loads issued for the NEXT tile) at the first barrier behind it.
 // Global data written before the barrier is NOT made visible by it (these kernels never hand global data between waves).
+#ifdef MS_ABL_NOBARRIER   // ablation (timing only, wrong results): what the workgroup barriers cost
+MS_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 MS_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 MS_DEV unsigned long long wave_shfl_xor(unsigned long long v, int mask) { return __shfl_xor(v, mask, 64); }
 MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { atomicMin(a, v); }
 MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { atomicMax(a, v); }
