@@ -209,6 +209,9 @@ struct Stark {
 
 // ------------------------------------------------------------------------------------------------
 // Verifier (CPU).  src/starks.rs:171-235, src/fri.rs:191-290, src/merkle.rs:312-338.
+// A PARITY MIRROR of the reference's verifier, NOT a sound verifier: like the reference it takes round 0's Merkle root from the proof
+// (it never enters the transcript), does not tie y3 of a window to y1 / the opening of the next window, does not check the last round
+// polynomial and only degree-bounds the shipped quotients.  "accepted" means "the reference's verifier would accept" (INTEGRATION.md 8).
 // ------------------------------------------------------------------------------------------------
 // nimue's Arthur: replays the prover's messages out of `arthur` into the same hash chain
 struct Arthur {

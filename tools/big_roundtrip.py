@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""prove on the GPU -> Stark::verify on the CPU at sizes the oracle does not reach:  python tools/big_roundtrip.py LOG_ROWS"""
+"""prove on the GPU -> Stark::verify on the CPU at sizes the oracle does not reach:  python tools/big_roundtrip.py LOG_ROWS
+"accepted" = the parity mirror of the REFERENCE's verifier accepts (a round-trip check of the prover's plumbing, not a soundness
+statement: the reference's FRI verifier leaves round 0's root, the window chaining and the last round unchecked)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mini_stark_amd as ms
