@@ -12,8 +12,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--log-rows", type=int, default=20)
 ap.add_argument("--field", type=int, default=0)
 ap.add_argument("--proofs", type=int, default=5)
+ap.add_argument("--lib", default=None, help="another build of libministark.so (experiments)")
 a = ap.parse_args()
-ctx = ms.Context(a.field)
+ctx = ms.Context(a.field, lib_path=a.lib)
 P = 2**64 - 2**32 + 1 if a.field == 0 else 2013265921
 N = 1 << a.log_rows
 tt = fibonacci_air(ctx, N - 1)
