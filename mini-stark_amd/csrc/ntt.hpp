@@ -544,6 +544,12 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #ifndef MS_NTT_PREFETCH
 #define MS_NTT_PREFETCH 0
 #endif
+#ifndef MS_NTT_XCD_LATER
+#define MS_NTT_XCD_LATER 1
+#endif
+#ifndef MS_NTT_STAGE_SRC
+#define MS_NTT_STAGE_SRC 1
+#endif
 #ifndef MS_NTT_VLOAD_UNROLL
 #define MS_NTT_VLOAD_UNROLL 4   // coefficient + twiddle gathers in flight per thread in the load of the pass behind the virtual pass
 #endif
@@ -595,9 +601,10 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     const size_t tiles = ((size_t)1 << (p.log_n - K)) >> LC, total = tiles * (size_t)p.nbatch;
     const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
     const bool do_scale = p.do_scale != 0;
-    // work items of this workgroup: g(i) for i = 0, 1, ..; behind the virtual pass XCD x = bx & 7 walks the contiguous range
-    // [x * total / 8, (x + 1) * total / 8) (its workgroups share 64-byte source lines through that XCD's L2)
-    const bool xcd_map = MODE == 2 && (nbx & 7) == 0 && (total & 7) == 0 && total >= 64;
+    // work items of this workgroup: g(i) for i = 0, 1, ..; XCD x = bx & 7 walks the contiguous range [x * total / 8, (x + 1) * total / 8):
+    // behind the virtual pass its workgroups share 64-byte source lines through that XCD's L2; in a later pass the 64 tiles an XCD works on
+    // at a time are 4 KiB runs of every row (measured: 264 -> 257 us per 6-column launch)
+    const bool xcd_map = (MODE == 2 || (MS_NTT_XCD_LATER && MODE == 1)) && (nbx & 7) == 0 && (total & 7) == 0 && total >= 64;
     const size_t stride = xcd_map ? (size_t)(nbx >> 3) : (size_t)nbx, first = xcd_map ? (size_t)(bx >> 3) : (size_t)bx;
     const size_t lim = xcd_map ? (total >> 3) : total, base_g = xcd_map ? (size_t)(bx & 7) * (total >> 3) : 0;
     if (first >= lim) return;
@@ -606,6 +613,22 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     size_t tl, by;
     locate(base_g + first, tiles, &tl, &by);
     if (PREFETCH) prefetch(p, tl, by, tid, rows, xs);
+    // behind the virtual pass the tile's R coefficients (one 8-byte gather each) are fetched ONE TILE AHEAD into NS registers per thread and
+    // handed to the expanding lanes through LDS (the row-twiddle region, free at that point): R gathers per tile instead of R * C broadcast loads
+    constexpr bool STAGE = MODE == 2 && !PREFETCH && MS_NTT_STAGE_SRC;
+    constexpr int NS = STAGE ? (R + TH - 1) / TH : 1;
+    T sv[NS];
+    auto stage_issue = [&](size_t tile_, size_t by_) {
+      const size_t nprime = ((size_t)1 << p.log_n) >> (LC + K);
+      const T* src = p.src + by_ * p.src_bstride;
+#pragma unroll
+      for (int j = 0; j < NS; j++) {
+        const int row = tid + j * TH;
+        const size_t k = tile_ + nprime * (size_t)row;     // k2 == the tile index
+        sv[j] = (row < R && k < p.n_in) ? src[k] : (T)0;
+      }
+    };
+    if (STAGE) stage_issue(tl, by);
     for (size_t it = first; it < lim; it += stride) {
       locate(base_g + it, tiles, &tl, &by);
       if (!PREFETCH && MODE != 2) prefetch(p, tl, by, tid, rows, xs);
@@ -617,11 +640,15 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         const size_t k_low_ = f0 >> p.log_Rp, i_done_ = (f0 & (((size_t)1 << p.log_Rp) - 1)) + c0;
         T* out_ = p.dst + by * p.dst_bstride + ((k_low_ << p.log_Rp) << K) + i_done_;
 #pragma unroll
+#ifdef MS_ABL_CONTIGWRITE
+        for (int i = 0; i < SWEEPS; i++) *reinterpret_cast<V16*>(p.dst + by * p.dst_bstride + (f0 << K) + (size_t)(rb * C + c0) + (size_t)(i * RPS) * C) = rows[i];
+#else
         for (int i = 0; i < SWEEPS; i++) *reinterpret_cast<V16*>(out_ + ((size_t)row_to_inew(rb + i * RPS) << p.log_Rp)) = rows[i];
+#endif
         continue;
       }
 #endif
-      if (row_tw) {
+      if (row_tw && !STAGE) {
         const size_t k_low = f0 >> p.log_Rp;
         for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);   // w_n^(k_low * Rp * i_new)
       }
@@ -642,17 +669,39 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         } else {
           const size_t n = (size_t)1 << p.log_n, k2 = f0 >> LC, nprime = n >> (LC + K);
           const T* src = p.src + by * p.src_bstride;
+          if constexpr (STAGE) {
+#pragma unroll
+            for (int j = 0; j < NS; j++) { const int row = tid + j * TH; if (row < R) twr[row] = sv[j]; }
+            msrt::wg_barrier();
+          }
 #pragma unroll MS_NTT_VLOAD_UNROLL
           for (int idx = tid; idx < R * C; idx += TH) {
             const int row = idx >> LC, i1 = idx & (C - 1);
             const size_t k = k2 + nprime * (size_t)row;
-            T v = (k < p.n_in) ? src[k] : (T)0;
+#ifdef MS_ABL_A_NOSRC
+            T v = (T)(k + 1);
+#else
+            T v = STAGE ? twr[row] : ((k < p.n_in) ? src[k] : (T)0);
+#endif
+#ifdef MS_ABL_A_NOVTW
+            if (i1) v = A::mul_tw(v, p.scale);
+#else
             if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
+#endif
             tile[tix(row, i1)] = v;
           }
         }
       }
       msrt::wg_barrier();
+      if (row_tw && STAGE) {   // the staged coefficients have been consumed: the region takes the row twiddles (read in the store phase)
+        const size_t k_low = f0 >> p.log_Rp;
+        for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);
+      }
+      if (STAGE && it + stride < lim) {   // next tile's coefficients: in flight during the sub-rounds and the store
+        size_t ntl, nby;
+        locate(base_g + it + stride, tiles, &ntl, &nby);
+        stage_issue(ntl, nby);
+      }
 #ifndef MS_ABL_NOCOMPUTE   // ablation builds (tools/ntt_ablate.sh): memory-only / compute-only timings of the same kernel
       sub_items<0, 0>(tid, tile, w);
 #endif
