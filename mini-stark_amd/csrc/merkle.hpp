@@ -457,7 +457,7 @@ struct PadOnlyBlockKernel {
 // nlevels > 1 the grid must be a single workgroup (fused tree top).
 // IC > 0: inner_children fixed at compile time (IC = 2 is the prover's tree, starks.rs:290-301: the padding block's
 // message schedule then folds to literals); IC = 0: taken from Params.
-struct InnerHashParams { u32* nodes; size_t child_off, nchildren; u32 ic; u32 nlevels; };
+struct InnerHashParams { u32* nodes; size_t child_off, nchildren; u32 ic; u32 nlevels; u32* host_root; /* optional: page-locked host memory that also receives the root (nparents == 1) */ };
 template <int IC> struct InnerHashKernelT {
   static constexpr int THREADS = msmerkle::THREADS;
   typedef InnerHashParams Params;
@@ -497,6 +497,7 @@ template <int IC> struct InnerHashKernelT {
       o0.x = bswap32(h.st[0]); o0.y = bswap32(h.st[1]); o0.z = bswap32(h.st[2]); o0.w = bswap32(h.st[3]);
       o1.x = bswap32(h.st[4]); o1.y = bswap32(h.st[5]); o1.z = bswap32(h.st[6]); o1.w = bswap32(h.st[7]);
       out[0] = o0; out[1] = o1;
+      if (p.host_root && nparents == 1) { uint4_t* hr = reinterpret_cast<uint4_t*>(p.host_root); hr[0] = o0; hr[1] = o1; }   // saves the caller a 32-byte copy launch
       if (stride == 0) break;
     }
   }

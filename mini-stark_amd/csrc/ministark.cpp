@@ -602,12 +602,18 @@ template <class F> struct Ctx : CtxBase {
     return 0;
   }
   // inner levels above `nchildren` digests at nodes[0..): level-major, root last (merkle.rs:131-140)
-  int inner_levels(u32* nodes, size_t nchildren, size_t ic) {
+  // `final_levels`: these levels end in the tree's root, which the last launch also stores to the page-locked slot host_root()
+  // (root_on_host: read_root / read_degree_and_root then need no copy launch, only the stream synchronisation they do anyway)
+  u32* host_root() const { return reinterpret_cast<u32*>(reinterpret_cast<u8*>(pinned) + 256); }
+  bool root_on_host = false;
+  int inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_levels = true) {
     size_t child_off = 0;
+    if (final_levels) root_on_host = false;
     while (nchildren > 1) {
       msmerkle::InnerHashKernel::Params ip;
-      ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic;
+      ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic; ip.host_root = nullptr;
       const size_t nparents = nchildren / ic;
+      if (final_levels && (nparents == 1 || nparents <= (size_t)tree_top_parents)) { ip.host_root = host_root(); root_on_host = true; }
       if (nparents <= (size_t)tree_top_parents) {  // fused tree top: one workgroup walks the remaining levels
         u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ic) nl++;
         ip.nlevels = nl;
@@ -637,7 +643,7 @@ template <class F> struct Ctx : CtxBase {
     RQ(exchange(MS_XCHG_ALL_TO_ALL, per * 32));
     msmerkle::InterleaveDigestsKernel::Params ik{reinterpret_cast<const msmerkle::uint4_t*>(xr), reinterpret_cast<msmerkle::uint4_t*>(nodes.p), per, (u32)W};
     CK(run<msmerkle::InterleaveDigestsKernel>(K_IO, grid1(Mloc * 2, msmerkle::InterleaveDigestsKernel::THREADS), 1, msmerkle::InterleaveDigestsKernel::THREADS, 0, ik));
-    RQ(inner_levels(nodes.as<u32>(), Mloc, 2));
+    RQ(inner_levels(nodes.as<u32>(), Mloc, 2, false));
     CK(msrt::d2d(xs, nodes.as<u8>() + (sub_nodes - 1) * 32, 32, stream));
     RQ(exchange(MS_XCHG_ALL_GATHER, 32));
     u8* top = nodes.as<u8>() + sub_nodes * 32;
@@ -646,10 +652,12 @@ template <class F> struct Ctx : CtxBase {
     ts.sharded = true; ts.Mloc = Mloc; ts.local_nodes = sub_nodes + top_nodes;
     return 0;
   }
+  // root of the tree built LAST on this context (every caller reads it right behind the build)
   int read_root(const DevBuf& nodes, const TreeShape& ts, u8* root) {
-    CK(msrt::d2h(pinned, nodes.as<u8>() + (ts.local_nodes - 1) * 32, 32, stream));
+    const bool on_host = root_on_host;
+    if (!on_host) CK(msrt::d2h(pinned, nodes.as<u8>() + (ts.local_nodes - 1) * 32, 32, stream));
     CK(msrt::sync(stream));
-    memcpy(root, pinned, 32);
+    memcpy(root, on_host ? reinterpret_cast<const void*>(host_root()) : pinned, 32);
     return 0;
   }
 
@@ -987,11 +995,10 @@ template <class F> struct Ctx : CtxBase {
         const int nb = (np - i0 < mspoly::MAX_POLYS) ? np - i0 : mspoly::MAX_POLYS;
         size_t off[mspoly::MAX_POLYS], cnt[mspoly::MAX_POLYS];
         for (int i = 0; i < nb; i++) { off[i] = 0; cnt[i] = N; }
-        RQ((eval_views<1>(d_polys.as<T>() + (size_t)i0 * N, N, 0, 1, off, cnt, nb, zz, d_small.as<T>() + ((size_t)t * np + i0) * E)));
+        RQ((eval_views<1>(d_polys.as<T>() + (size_t)i0 * N, N, 0, 1, off, cnt, nb, zz, reinterpret_cast<T*>(pinned) + ((size_t)t * np + i0) * E)));   // results land in page-locked host memory
       }
     }
     if (tot) {
-      CK(msrt::d2h(pinned, d_small.p, tot * sizeof(T), stream));
       CK(msrt::sync(stream));
       const T* h = reinterpret_cast<const T*>(pinned);
       for (size_t i = 0; i < tot; i++) out[i] = F::to_u64(h[i]);
@@ -1064,11 +1071,12 @@ template <class F> struct Ctx : CtxBase {
       typename mspoly::DegreeKernel<F, E>::Params dp{poly, limb_stride, n, dres};
       CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
     }
+    const bool on_host = r && root_on_host;   // r's tree is the one built last (round_commit just before)
     CK(msrt::d2h(pinned, dres, 8, stream));
-    if (r) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, r->nodes.template as<u8>() + (r->ts.local_nodes - 1) * 32, 32, stream));
+    if (r && !on_host) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, r->nodes.template as<u8>() + (r->ts.local_nodes - 1) * 32, 32, stream));
     CK(msrt::sync(stream));
     *ncoef = (size_t)(*reinterpret_cast<unsigned long long*>(pinned));
-    if (r && root) memcpy(root, reinterpret_cast<u8*>(pinned) + 64, 32);
+    if (r && root) memcpy(root, on_host ? reinterpret_cast<const u8*>(host_root()) : reinterpret_cast<const u8*>(pinned) + 64, 32);
     return 0;
   }
   // fri.rs:73-82
@@ -1102,9 +1110,8 @@ template <class F> struct Ctx : CtxBase {
     if (!load_ext(z, &cur_z)) return fail(MS_ERR_ARG, "z not canonical");
     Round* r = rounds[nrounds_done - 1];
     size_t off[2] = {0, 1}, cnt[2] = {(r->ncoef + 1) / 2, r->ncoef / 2};
-    T* dst = d_small.as<T>();
+    T* dst = reinterpret_cast<T*>(pinned);   // the last kernel of the evaluation stores its 2 E words straight into page-locked host memory
     RQ((eval_views<E>(r->poly.template as<T>(), 0, r->cap, 2, off, cnt, 2, cur_z, dst)));  // fri.rs:354-359
-    CK(msrt::d2h(pinned, dst, 2 * E * sizeof(T), stream));
     CK(msrt::sync(stream));
     const T* h = reinterpret_cast<const T*>(pinned);
     for (int s = 0; s < 2; s++) for (int l = 0; l < E; l++) { cur_B[s].c[l] = h[s * E + l]; B[s * E + l] = F::to_u64(h[s * E + l]); }
