@@ -72,6 +72,8 @@ class Lanes:
             self.d_traces = [torch.from_numpy(t.data.view(np.int64)).to(dev) for t in self.tts]  # resident in HBM before the timed region
         torch.cuda.synchronize()
         self.last = [None] * inflight
+        if os.environ.get("MS_BENCH_DUMP_MAPS"):   # debugging aid: the address map of this process (to resolve a crash's raw frames)
+            open(os.environ["MS_BENCH_DUMP_MAPS"], "w").write(open("/proc/self/maps").read())
 
     def _prove_n(self, i, n):
         ptr = None if self.io else self.d_traces[i].data_ptr()
@@ -90,6 +92,8 @@ class Lanes:
             t.join()
 
     def timed(self, grp, steps, warmup):
+        if self.n > 1:
+            self._prove_n(0, 1)   # untimed: every kernel's first launch (HIP loads code objects lazily) happens on ONE thread before the lanes start
         self.run(warmup)
         grp.barrier()
         t0 = time.perf_counter()

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Turns gpurun_out/prof_<round>/ (tools/profile_round.sh) into the committed summaries under profiles/."""
-import csv, glob, json, collections, shutil, sys
+import csv, glob, json, collections, os, shutil, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 O = f"gpurun_out/prof_{R}"
-one = lambda pat: sorted(glob.glob(pat))[-1]
+one = lambda pat: max(glob.glob(pat), key=os.path.getmtime)   # gpurun merges every call's output into the same tree: take the newest
 shutil.copy(one(O + "/stats/*/*kernel_stats.csv"), f"profiles/{R}_kernel_stats.csv")
 shutil.copy(one(O + "/stats1/*/*kernel_stats.csv"), f"profiles/{R}_kernel_stats_inflight1.csv")
 bench = [json.loads(l) for l in open(O + "/bench_default.json") if l.startswith("{")][-1]
@@ -15,17 +15,60 @@ for l in open(O + "/stats1.log"):
     if l.startswith("{"):
         d = json.loads(l)
         print("bench   (1 proof in flight) roofline", d["roofline"]["kernel"], "avg_launch_ms", d["roofline"]["avg_launch_ms"], "proofs/s", d["value"])
-def load(path, name):
-    return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if KN in r["Kernel_Name"] and r["Counter_Name"] == name]
-f = load(one(O + "/pmc_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
-w = load(one(O + "/pmc_write/*/*counter_collection.csv"), "WRITE_SIZE")
-n = len(f); fetch = sum(f) * 1024 * 2 / n; write = sum(w) * 1024 / n
-json.dump(dict(kernel="msntt::" + KN, round=R, launches=n, fetch_bytes_per_launch_corrected=fetch, write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write,
-               method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline` (2 proofs); "
-                      "counter unit KB (x1024); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), confirmed in r01a: an LDE pass writes 393216 KB = "
-                      "6*2^23*8 B exactly while its raw FETCH_SIZE reads 197059 KB (half of the 402.65 MB it loads). Per-launch average over this kernel's launches only.",
-               raw=dict(fetch_kb=f, write_kb=w)), open(f"profiles/{R}_pmc_ntt_pass.json", "w"), indent=1)
-print("traffic/launch MB", (fetch + write) / 1e6, "launches", n)
+# ---- HBM traffic of every NTT pass kernel (FETCH_SIZE / WRITE_SIZE passes), per launch, with the calibration each access pattern needs
+def per_dispatch(path, name):
+    out = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        if "PassKernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            out.setdefault(r["Kernel_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    return {k: [v for _, v in sorted(l)] for k, l in out.items()}
+def durations(tracefile):
+    out = collections.OrderedDict()
+    for r in sorted(csv.DictReader(open(tracefile)), key=lambda r: int(r["Dispatch_Id"])):
+        if "PassKernel" in r["Kernel_Name"]:
+            out.setdefault(r["Kernel_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return out
+F = per_dispatch(one(O + "/pmc_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
+W = per_dispatch(one(O + "/pmc_write/*/*counter_collection.csv"), "WRITE_SIZE")
+D = durations(one(O + "/pmc_fetch/*/*kernel_trace.csv"))
+short = lambda n: "msntt::" + n[n.index("PassKernel"):].split(" >(")[0].split(">(")[0]
+variants = {}
+for k in F:
+    f, w, d = F[k], W.get(k, []), D.get(k, [])
+    n = min(len(f), len(w), len(d))
+    if not n:
+        continue
+    name = short(k)
+    # FETCH_SIZE tallies a 128-byte request as 64 bytes (guide) and a 64-byte request as 64: calibrated per kernel on a known byte count.  A plain or later
+    # pass (modes 0, 1) reads exactly as many bytes as it writes, and WRITE_SIZE is exact: the factor is 2 when the raw count is half of that (both halves of
+    # a line asked for by the same XCD's L2: the XCD-contiguous tile walk), 1 when it equals it (r02's first walk: neighbouring 64-byte pieces went to
+    # different XCDs).  Mode 2 (8-byte gathers + L2-resident tables): the guide's x2 kept as an upper bound.
+    mode2 = name.rstrip(">").rstrip().endswith(", 2")
+    corr = 2.0 if mode2 or sum(f[:n]) < 0.75 * sum(w[:n]) else 1.0
+    per = [dict(fetch_raw_bytes=f[i] * 1024, fetch_bytes=f[i] * 1024 * corr, write_bytes=w[i] * 1024, hbm_bytes=f[i] * 1024 * corr + w[i] * 1024, us_in_pmc_run=d[i],
+                TBps_on_traffic=(f[i] * 1024 * corr + w[i] * 1024) / d[i] / 1e6) for i in range(n)]
+    hb = sum(x["hbm_bytes"] for x in per) / n; us = sum(d[:n]) / n
+    variants[name] = dict(fetch_correction=corr, launches=n, hbm_bytes_per_launch=hb, avg_us=us, TBps_on_traffic=hb / us / 1e6, per_launch=per)
+roof = "msntt::" + KN if not KN.startswith("msntt::") else KN
+rv = variants.get(roof) or next(iter(variants.values()))
+s8 = 8
+alg = dict(lde_3_columns=3 * ((1 << 20) + (1 << 23)) * s8, fri_round0_1_column=((1 << 20) + (1 << 23)) * s8)
+big = lambda name: max(x["hbm_bytes"] for x in variants[name]["per_launch"]) if name in variants else 0.0   # the 3-column launch of that kernel
+lde_traffic = sum(big(n) for n in variants if ", false," in n and (n.rstrip(">").rstrip().endswith(", 2") or n.rstrip(">").rstrip().endswith(", 1")))
+json.dump(dict(kernel=roof, round=R, launches=rv["launches"], hbm_bytes_per_launch=rv["hbm_bytes_per_launch"],
+               method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-extras` "
+                      "(2 proofs: per proof one 3-column LDE and one 1-column FRI round-0 transform, each two launches; plus the 3-column INTT). Counter unit KB (x1024). "
+                      "FETCH_SIZE calibration (MI355X_MICROARCH.md: a 128-byte request is tallied as 64 bytes; other patterns to be calibrated on a known byte count): a plain or later pass "
+                      "(modes 0, 1) reads exactly the bytes it writes (WRITE_SIZE is exact), so fetch_correction = 2 where the raw count is half of that - the later passes since the "
+                      "XCD-contiguous tile walk, where one L2 asks for both 64-byte halves of a line: raw 101.2 MB for the 201.3 MB a 3-column launch reads - and 1 where it equals it "
+                      "(the first plain pass: raw 25.4 MB for 25.2 MB; before the new walk also the later passes: raw 201.5 MB). The pass behind the virtual zero-padding pass (mode 2) gathers "
+                      "8-byte coefficients (25.2 MB of them, each 64-byte line shared by 8 tiles of one XCD) plus L2-resident twiddle tables; the guide's factor 2 is kept there as an upper bound "
+                      "(about a tenth of that launch's bytes either way). WRITE_SIZE is exact. Written by tools/process_profiles.py.",
+               algorithmic_bytes=alg, traffic_over_algorithmic=dict(lde_3_columns=lde_traffic / alg["lde_3_columns"]), variants=variants),
+          open(f"profiles/{R}_pmc_ntt_pass.json", "w"), indent=1)
+print("roofline kernel traffic/launch MB", rv["hbm_bytes_per_launch"] / 1e6, "launches", rv["launches"], "LDE traffic / algorithmic", lde_traffic / alg["lde_3_columns"])
+for n, v in variants.items():
+    print("  ", n, "avg_us %.1f  MB/launch %.1f  TB/s on traffic %.2f" % (v["avg_us"], v["hbm_bytes_per_launch"] / 1e6, v["TBps_on_traffic"]))
 rows = list(csv.DictReader(open(one(O + "/pmc_sq/*/*counter_collection.csv"))))
 tr = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(one(O + "/pmc_sq/*/*kernel_trace.csv")))}
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -44,7 +87,7 @@ try:
     shutil.copy(O + "/valu_rate.txt", f"profiles/{R}_valu_issue_rate.txt")
 except Exception:
     pass
-for extra in ("ntt_lab.log",):
+for extra in ("ntt_lab.log", "latency_probe.txt"):
     try:
         shutil.copy(O + "/" + extra, f"profiles/{R}_" + extra)
     except Exception:

@@ -13,4 +13,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-extras > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-extras > $O/pmc_sq.log 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate > $O/valu_rate.txt 2>&1 || true   # built from source every time (the binary is not tracked)
+hipcc --offload-arch=gfx950 -O2 tools/latency_probe.hip -o /tmp/latency_probe 2>/dev/null && timeout -k 5 120 /tmp/latency_probe > $O/latency_probe.txt 2>&1 || true
 ls $O
