@@ -230,6 +230,8 @@ def main():
         lanes.close()
         lanes = None
         done = threading.Event()
+        if rank == 0:   # stderr only (stdout carries exactly one JSON line): the headline survives in the log even if the next leg takes the process down
+            print(f"[bench] replicas leg done: {out['value']:.2f} proofs/s on {world} GPUs; starting the sharded leg", file=sys.stderr, flush=True)
 
         def watchdog():
             if not done.wait(args.shard_timeout):
