@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "field.hpp"
@@ -266,7 +267,8 @@ template <class F> struct Ctx : CtxBase {
     for (auto& kv : sub_ms) {
       const int sub = kv.first; char name[160], buf[320];
       const char* fld = F::ID == 0 ? "GL" : "BB";
-      if (sub & 128) snprintf(name, sizeof name, "msntt::PassKernel2<%s, %s, %s, %d, %d, %d, %d, %d>", fld, (sub & 2048) ? "GLM" : (F::ID == 0 ? "GLT" : "BB"), (sub & 64) ? "true" : "false",
+      if (sub & 16384) snprintf(name, sizeof name, "msntt::RegPassKernel<%s, %s, %s, %d>", fld, F::ID == 0 ? "GLM" : "BB", (sub & 64) ? "true" : "false", sub & 15);
+      else if (sub & 128) snprintf(name, sizeof name, "msntt::PassKernel2<%s, %s, %s, %d, %d, %d, %d, %d>", fld, (sub & 2048) ? "GLM" : (F::ID == 0 ? "GLT" : "BB"), (sub & 64) ? "true" : "false",
                               sub & 15, (sub >> 8) & 7, (sub & 2048) ? (((sub >> 8) & 7) == 4 ? 1024 : ((sub & 15) == 8 ? 256 : 512)) : 256, (sub & 2048) ? 3 : 2, (sub >> 12) & 3);
       else if (sub & 32) snprintf(name, sizeof name, "msntt::PassKernel<%s, %s, %d>", fld, (sub & 64) ? "true" : "false", (sub & 16) ? 512 : 256);
       else snprintf(name, sizeof name, "msntt::PassKernelK<%s, %s, %d, %d>", fld, (sub & 64) ? "true" : "false", sub & 15, (sub & 16) ? 512 : 256);
@@ -283,13 +285,14 @@ template <class F> struct Ctx : CtxBase {
     int log_n = 0, log_r0 = 0, log_rho = 0, npass = 0, K[4] = {0, 0, 0, 0}, lo_bits = 0;
     int LC[4] = {msntt::TILE_LOG_C, msntt::TILE_LOG_C, msntt::TILE_LOG_C, msntt::TILE_LOG_C};   // log2 tile columns of every pass
     bool v2[4] = {false, false, false, false};                                                   // pass runs on msntt::PassKernel2
+    bool regp[4] = {false, false, false, false};                                                 // pass runs on msntt::RegPassKernel (last pass, radix <= 32, registers only)
     DevBuf tw_lo, tw_hi, w_r[4], vtw, w0;
     T n_inv = 0;
   };
   std::map<int, Plan*> plans;  // key = (log_n*4 + log_pad)*2 + inverse
   DevBuf ntt_scratch;
   int ntt_kmax = 9;            // largest tile (log2 rows) of a multi-pass plan; MS_NTT_KMAX overrides (tuning)
-  int ntt_v2 = 1, ntt_v2_min = 14, ntt_v2_maxpass = 2, ntt_v2_sub3 = 1, ntt_v2_wide = 0;   // MS_NTT_V2=0: round-1 kernels only (A/B); transforms of at least 2^MS_NTT_V2_MIN points use the two-sub-round tiles
+  int ntt_v2 = 1, ntt_v2_min = 14, ntt_v2_maxpass = 2, ntt_v2_sub3 = 1, ntt_v2_wide = 0, ntt_v2_regpass = 1;   // MS_NTT_V2=0: round-1 kernels only (A/B); transforms of at least 2^MS_NTT_V2_MIN points use the two-sub-round tiles
   int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1, ntt_fast = 1, ntt_fast_min = 22, ntt_fast_max = 24;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
 
   // log_pad: the input is zero beyond n >> log_pad
@@ -306,7 +309,16 @@ template <class F> struct Ctx : CtxBase {
     if ((F::ID == 0 ? ntt_v2 >= 1 : ntt_v2 >= 2) && log_n >= ntt_v2_min && log_n > msntt::MAX_LOG_R && (log_pad == 0 || log_pad == 3)) {
       // passes of up to 2^10 rows; a blowup-8 evaluation starts behind the virtual radix-8 zero-padding pass (8 tile columns = its 8 cosets)
       const int m = log_n - log_pad, P = (m + 9) / 10;
-      if (P <= ntt_v2_maxpass && m / P >= 7) {   // measured (r02): two passes of 2^10-row tiles beat three of 2^8; with three or more passes the round-1 tiles win
+      const int kb = (ntt_v2_regpass == 2) ? 7 : 10;   // MS_NTT_V2_REGPASS=2 (tests): the same plan shape on 2^7-row tiles, so that 2^15..2^19 points exercise every register radix
+      if (ntt_v2_regpass && m - 2 * kb >= 1 && m - 2 * kb <= 5) {
+        // 2^21..2^25 non-zero points: 2^10 x 2^10 on the large tiles, then the remaining 2^(m-20) points of every output in registers - a streaming
+        // pass at copy speed instead of a third tile pass (MS_NTT_V2_REGPASS=0: the three-pass plan of 2^8-row round-1 tiles)
+        use_v2 = true;
+        pl->log_rho = 0; pl->log_r0 = log_pad; pl->npass = 3;
+        pl->K[0] = kb; pl->K[1] = kb; pl->K[2] = m - 2 * kb;
+        pl->LC[0] = log_pad ? 3 : v2_lc; pl->LC[1] = v2_lc; pl->LC[2] = 0;
+        pl->v2[0] = pl->v2[1] = true; pl->regp[2] = true;
+      } else if (P <= ntt_v2_maxpass && m / P >= 7) {   // measured (r02): two passes of 2^10-row tiles beat three of 2^8; with three or more passes the round-1 tiles win
         use_v2 = true;
         pl->log_rho = 0; pl->log_r0 = log_pad; pl->npass = P;
         for (int i = 0; i < P; i++) {
@@ -451,8 +463,25 @@ template <class F> struct Ctx : CtxBase {
       default: return 999;
     }
   }
+  template <bool INV, int K>
+  int launch_reg(const msntt::PassParams<F>& pp, size_t batch) {
+    typedef msntt::RegPassKernel<F, typename std::conditional<F::ID == 0, GLM, F>::type, INV, K> KK;
+    if (!KK::applicable(pp)) return 995;
+    next_sub = K | 16384 | (INV ? 64 : 0);
+    return run<KK>(K_NTT_PASS, KK::grid(pp), (unsigned)batch, KK::THREADS, 0, pp);
+  }
   template <bool INV>
-  int launch_pass(const msntt::PassParams<F>& pp, size_t tiles, size_t batch, bool v2 = false) {
+  int launch_pass(const msntt::PassParams<F>& pp, size_t tiles, size_t batch, bool v2 = false, bool regp = false) {
+    if (regp) {
+      switch (pp.log_r) {
+        case 1: return launch_reg<INV, 1>(pp, batch);
+        case 2: return launch_reg<INV, 2>(pp, batch);
+        case 3: return launch_reg<INV, 3>(pp, batch);
+        case 4: return launch_reg<INV, 4>(pp, batch);
+        case 5: return launch_reg<INV, 5>(pp, batch);
+        default: return 994;
+      }
+    }
     if (v2) {
       if constexpr (F::ID == 0) return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : (pp.log_r == 10 && pp.log_C == 4 ? launch_v2<INV, 10, 4>(pp, tiles, batch) : 997);
       else return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : launch_v2k<INV, 4>(pp, tiles, batch);
@@ -526,7 +555,7 @@ template <class F> struct Ctx : CtxBase {
       pp.last = (k == P - 1); pp.nbatch = (u32)batch;
       const size_t tiles = ((size_t)1 << cols_log) >> pp.log_C;
       next_bytes = (double)(n_in + n) * batch * sizeof(T) / P;  // (n_in + n)*s per transform, shared by its P real passes
-      if (inverse) CK(launch_pass<true>(pp, tiles, batch, pl->v2[k])); else CK(launch_pass<false>(pp, tiles, batch, pl->v2[k]));
+      if (inverse) CK(launch_pass<true>(pp, tiles, batch, pl->v2[k], pl->regp[k])); else CK(launch_pass<false>(pp, tiles, batch, pl->v2[k], pl->regp[k]));
       in = out; in_bs = out_bs;
       log_Rp += pl->K[k];
     }
@@ -699,6 +728,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_V2")) ntt_v2 = atoi(e);
     if (const char* e = getenv("MS_NTT_V2_SUB3")) ntt_v2_sub3 = atoi(e);
     if (const char* e = getenv("MS_NTT_V2_WIDE")) ntt_v2_wide = atoi(e);
+    if (const char* e = getenv("MS_NTT_V2_REGPASS")) ntt_v2_regpass = atoi(e);
     if (const char* e = getenv("MS_NTT_COOP_WGS")) { int v = atoi(e); if (v >= 8 && v <= 65536) ntt_coop_wgs = v & ~7; }
     if (const char* e = getenv("MS_NTT_V2_MAXPASS")) { int v = atoi(e); if (v >= 1 && v <= 4) ntt_v2_maxpass = v; }
     if (const char* e = getenv("MS_NTT_V2_MIN")) { int v = atoi(e); if (v >= 12 && v <= 32) ntt_v2_min = v; }

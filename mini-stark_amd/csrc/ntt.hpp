@@ -770,6 +770,63 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
   }
 };
 
+// LAST pass of a small radix (2^K <= 32 points), whole DFT in registers: the rows of this pass are contiguous runs of n / 2^K elements,
+// so a lane takes VEC neighbouring columns, loads their 2^K row elements (16-byte loads, fully coalesced), transforms, stores.  No LDS, no
+// twiddle tables for Goldilocks (radix <= 64 twiddles are shifts).  A streaming kernel: it lets a 2^21..2^25-point transform run as
+// 2^10 x 2^10 x 2^K (two passes on the large cooperative tiles + this copy-speed pass) instead of three passes of 2^8-row tiles.
+template <class F, class A, bool INV, int K> struct RegPassKernel {
+  typedef typename F::T T;
+  typedef PassParams<F> Params;
+#ifndef MS_REG_TH
+#define MS_REG_TH 128   // measured at 2^27 points x 6 columns: 64..128 threads 2.56-2.59 ms, 256 threads 2.98 ms, 512 threads 2.70 ms (8-byte accesses: 2.58-3.0 ms)
+#endif
+#ifndef MS_REG_VECMAXK
+#define MS_REG_VECMAXK 4
+#endif
+  static constexpr int THREADS = MS_REG_TH;
+  static constexpr int R = 1 << K;
+  static constexpr int VEC = (K <= MS_REG_VECMAXK) ? 16 / (int)sizeof(T) : 1;     // 2^K * VEC elements per lane stay in registers
+  typedef T V16 __attribute__((vector_size(16)));
+  static_assert(K >= 1 && K <= 5, "register pass radix");
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_HD bool applicable(const Params& p) {
+    return (int)p.log_r == K && p.last && p.log_r0 == 0 && p.log_rho == 0 && (int)p.log_Rp == (int)p.log_n - K && p.n_in >= ((size_t)1 << p.log_n) &&
+           ((size_t)1 << p.log_Rp) % VEC == 0;
+  }
+  static MS_HD unsigned grid(const Params& p) { return (unsigned)(((((size_t)1 << p.log_Rp) / VEC) + THREADS - 1) / THREADS); }
+  static MS_DEV void phase(int, const Params& p, int bx, int by, int tid, int, unsigned char*) {
+    const size_t cs = (size_t)1 << p.log_Rp;                         // n / 2^K: row length = distance between the points of one DFT
+    const size_t i = ((size_t)bx * THREADS + tid) * VEC;
+    if (i >= cs) return;
+    const T* src = p.src + (size_t)by * p.src_bstride + i;
+    T* dst = p.dst + (size_t)by * p.dst_bstride + i;
+    const bool do_scale = p.do_scale != 0;
+    if constexpr (VEC > 1) {
+      V16 v[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) v[k] = *reinterpret_cast<const V16*>(src + (size_t)k * cs);
+#pragma unroll
+      for (int c = 0; c < VEC; c++) {
+        T x[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) x[k] = v[k][c];
+        dif_regs<A, INV, K>(x, p.w_r, K);
+#pragma unroll
+        for (int e = 0; e < R; e++) { T y = x[bitrev(e, K)]; if (do_scale) y = A::mul_tw(y, p.scale); v[e][c] = y; }   // v[k][c] are all consumed: reuse as the output rows
+      }
+#pragma unroll
+      for (int e = 0; e < R; e++) *reinterpret_cast<V16*>(dst + (size_t)e * cs) = v[e];
+    } else {
+      T x[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) x[k] = src[(size_t)k * cs];
+      dif_regs<A, INV, K>(x, p.w_r, K);
+#pragma unroll
+      for (int e = 0; e < R; e++) { T y = x[bitrev(e, K)]; if (do_scale) y = A::mul_tw(y, p.scale); dst[(size_t)e * cs] = y; }
+    }
+  }
+};
+
 // out[k] = in[k] * s^k  (k < n) — the coset pre-scaling of
 // Radix2EvaluationDomain::get_coset(shift).fft (starks.rs:82-89).
 template <class F> struct ScalePowKernel {

@@ -161,3 +161,26 @@ def test_babybear_on_the_round2_tiles(mk, monkeypatch):
     fresh = lambda f, fresh=False: mk(f, fresh=True)
     pc.case_ntt(fresh, 1, 16)
     pc.case_coset_lde(fresh, 1, 14, 8)
+
+
+@pytest.mark.parametrize("v2", ["1", "2"])
+def test_ntt_register_last_pass(mk, monkeypatch, v2):
+    """Plans 2^K x 2^K x 2^j with the last 2^j points of every output done in registers (msntt::RegPassKernel): MS_NTT_V2_REGPASS=2 puts
+    the plan on 2^7-row tiles, so that 2^15..2^19 points walk every register radix (j = 1..5), forward, inverse and behind the virtual
+    zero-padding pass.  v2 = 2 runs BabyBear on the cooperative tiles too."""
+    monkeypatch.setenv("MS_NTT_V2_REGPASS", "2")
+    monkeypatch.setenv("MS_NTT_V2", v2)
+    fresh = lambda f, fresh=False: mk(f, fresh=True)
+    fields = (0, 1) if v2 == "2" else (0,)
+    for field in fields:
+        for log_n in (15, 16, 17, 18, 19):
+            pc.case_ntt(fresh, field, log_n, batch=1)
+        for log_n, blowup in ((12, 8), (14, 8), (16, 8)):    # m = log_n: j = ... behind the virtual radix-8 pass (12: not this plan; 15, 17: j = 1, 3 via 2^15 / 2^17 below)
+            pc.case_coset_lde(fresh, field, log_n, blowup)
+        pc.case_coset_lde(fresh, field, 15, 8)
+        pc.case_coset_lde(fresh, field, 17, 8)
+
+
+def test_ntt_register_last_pass_full_tiles(mk):
+    """The shipped shape: 2^10 x 2^10 x 2 on a 2^21-point transform (default knobs)."""
+    pc.case_ntt(lambda f, fresh=False: mk(f, fresh=True), 0, 21, batch=1)
