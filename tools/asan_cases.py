@@ -25,4 +25,10 @@ for field in (0, 1):
     pc.case_prove_wide(mk, field, log_n=6, w=64)
     pc.case_general_closure(mk, field)
     pc.case_merkle_prove(mk, field)
+# register-only last pass (msntt::RegPassKernel) on the test plan shape: every register radix, forward / inverse / behind the virtual pass
+os.environ["MS_NTT_V2_REGPASS"] = "2"
+for log_n in (15, 16, 17, 18, 19):
+    pc.case_ntt(lambda f, fresh=False: mk(f, fresh=True), 0, log_n, batch=1)
+pc.case_coset_lde(lambda f, fresh=False: mk(f, fresh=True), 0, 15, 8)
+del os.environ["MS_NTT_V2_REGPASS"]
 print("asan run complete")
