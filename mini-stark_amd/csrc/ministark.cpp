@@ -101,6 +101,8 @@ template <class F> struct Ctx : CtxBase {
 
   int device = 0, zae = 1, trace_mont = 0;
   int lde_linear = 1;  // MS_LDE_LINEAR=0 disables the linear-provenance shortcut of lde_compute (A/B measurements)
+  int lde_multi = 0;   // MS_LDE_MULTI=1: the linear LDE columns in shared sweeps (LincombMultiKernel).  Measured (r02): 45 us less per proof alone (6 column
+                       // transfers instead of 10), but 248 -> 240 proofs/s with 8 proofs in flight (five interleaved runs each), so it is off by default
   int tree_top_parents = msmerkle::THREADS;  // MS_TREE_TOP: levels of at most this many parents are walked by one workgroup in one launch (measured: 256 beats 1024 by 3 % in latency)
   int leaf_lazy_min = 16;  // MS_LEAF_LAZY_MIN: leaf groups of at least this many base limbs use the wave-synchronous two-block leaf kernel
   int fri_pointwise = 1;  // MS_FRI_POINTWISE=0: codewords of FRI rounds >= 1 by NTT of the round polynomial instead of the evaluation-domain fold
@@ -733,6 +735,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_V2_MAXPASS")) { int v = atoi(e); if (v >= 1 && v <= 4) ntt_v2_maxpass = v; }
     if (const char* e = getenv("MS_NTT_V2_MIN")) { int v = atoi(e); if (v >= 12 && v <= 32) ntt_v2_min = v; }
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
+    if (const char* e = getenv("MS_LDE_MULTI")) lde_multi = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
     if (const char* e = getenv("MS_LEAF_LAZY_MIN")) leaf_lazy_min = atoi(e);
     if (const char* e = getenv("MS_TREE_TOP")) { int v = atoi(e); if (v >= 1 && v <= 65536) tree_top_parents = v; }
@@ -866,6 +869,51 @@ template <class F> struct Ctx : CtxBase {
     }
     return 0;
   }
+  // The LDE columns of all polynomials with linear provenance (columns `stride` apart, n elements each).  Consecutive ones whose sources
+  // are all transformed columns (no linear column among them) and fit LincombMultiKernel (<= 4 outputs over <= 8 distinct sources) share
+  // one sweep; anything else goes through lincomb_into one by one.
+  int lincomb_linear_columns(T* base, size_t stride, size_t n) {
+    const size_t c = (size_t)npolys;
+    typedef mspoly::LincombMultiKernel<F> MK;
+    typename MK::Params mp; int nout = 0, nsrc = 0;
+    auto flush = [&]() -> int {
+      if (!nout) return 0;
+      mp.polys = base; mp.stride = stride; mp.n = n; mp.nout = nout; mp.nsrc = nsrc;
+      next_bytes = (double)(nout + nsrc) * n * sizeof(T);
+      int e = run<MK>(K_LINCOMB, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, mp);
+      nout = nsrc = 0;
+      return e;
+    };
+    for (size_t i = 0; i < c; i++) {
+      const Lin& li = poly_lin[i];
+      if (li.idx.empty()) continue;
+      bool simple = lde_multi && li.idx.size() <= (size_t)mspoly::LCM_SRC;
+      for (int ix : li.idx) if (ix < 0 || (size_t)ix >= c || !poly_lin[ix].idx.empty()) simple = false;   // a source that is itself a linear column: keep the order
+      if (simple) {
+        for (int attempt = 0; attempt < 2; attempt++) {
+          int map[mspoly::LCM_SRC], ns = nsrc; bool fits = nout < mspoly::LCM_OUT;
+          int srcs[mspoly::LCM_SRC]; for (int u = 0; u < nsrc; u++) srcs[u] = mp.src[u];
+          for (size_t t = 0; fits && t < li.idx.size(); t++) {
+            int u = 0; while (u < ns && srcs[u] != li.idx[t]) u++;
+            if (u == ns) { if (ns == mspoly::LCM_SRC) { fits = false; break; } srcs[ns++] = li.idx[t]; }
+            map[t] = u;
+          }
+          if (!fits) { CK(flush()); continue; }   // second attempt on an empty group always fits (<= LCM_SRC terms)
+          for (int u = nsrc; u < ns; u++) mp.src[u] = srcs[u];
+          for (int u = 0; u < mspoly::LCM_SRC; u++) mp.m[nout][u] = 0;
+          for (size_t t = 0; t < li.idx.size(); t++) mp.m[nout][map[t]] = F::add(mp.m[nout][map[t]], F::from_u64(li.s[t] % F::P));   // a column named twice: coefficients add up
+          mp.dst[nout] = base + i * stride;
+          nsrc = ns; nout++;
+          break;
+        }
+      } else {
+        CK(flush());
+        RQ(lincomb_into(base, stride, n, li.s.data(), li.idx.data(), (int)li.idx.size(), (int)i, base + i * stride));
+      }
+    }
+    CK(flush());
+    return 0;
+  }
   // starks.rs:80-91.  The coset evaluation is linear, so a polynomial that ms_polys_lincomb defined as
   // sum_t s_t * P_idx[t] has LDE column sum_t s_t * LDE(P_idx[t]): only polynomials without such provenance
   // (the trace columns, ms_polys_append uploads) go through the NTT.
@@ -885,10 +933,7 @@ template <class F> struct Ctx : CtxBase {
       RQ(ntt_run(ctz64(L_), false, d_coef.as<T>() + i * N, N, N, d_lde.as<T>() + i * L_, L_, j - i));
       i = j;
     }
-    if (lde_linear)
-      for (size_t i = 0; i < c; i++)
-        if (!poly_lin[i].idx.empty())
-          RQ(lincomb_into(d_lde.as<T>(), L_, L_, poly_lin[i].s.data(), poly_lin[i].idx.data(), (int)poly_lin[i].idx.size(), (int)i, d_lde.as<T>() + i * L_));
+    if (lde_linear) RQ(lincomb_linear_columns(d_lde.as<T>(), L_, L_));
     return 0;
   }
   // Evaluations of `batch` polynomials (ncoef coefficients each) on this rank's share of the size-2^log_D domain shift*<w_D>:
@@ -922,10 +967,7 @@ template <class F> struct Ctx : CtxBase {
       RQ(coset_eval(d_polys.as<T>() + i * N, N, N, ctz64(L_), F::from_u64(shift), 1, d_lde.as<T>() + i * m, m, j - i));
       i = j;
     }
-    if (lde_linear)
-      for (size_t i = 0; i < c; i++)
-        if (!poly_lin[i].idx.empty())
-          RQ(lincomb_into(d_lde.as<T>(), m, m, poly_lin[i].s.data(), poly_lin[i].idx.data(), (int)poly_lin[i].idx.size(), (int)i, d_lde.as<T>() + i * m));
+    if (lde_linear) RQ(lincomb_linear_columns(d_lde.as<T>(), m, m));
     return 0;
   }
   int lde_commit(size_t blowup_, u64 shift, size_t lpn, u8* root) override {

@@ -91,6 +91,33 @@ template <class F> struct LincombKernel {
     p.dst[j] = acc;
   }
 };
+// Several linear combinations of the SAME few columns in one sweep: out[o][j] = sum_u m[o][u] * col[src[u]][j].  Every source element is
+// loaded once for all outputs (the three constraint columns of the Fibonacci LDE: 6 column transfers instead of 10).  m is uniform over the
+// launch, so the zero tests are scalar branches; field addition is exact, so the order of the terms does not matter.
+constexpr int LCM_SRC = 8, LCM_OUT = 4;
+template <class F> struct LincombMultiKernel {
+  typedef typename F::T T;
+  static constexpr int THREADS = mspoly::THREADS;
+  struct Params { const T* polys; size_t stride, n; T* dst[LCM_OUT]; int src[LCM_SRC]; T m[LCM_OUT][LCM_SRC]; int nsrc, nout; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
+    const size_t j = (size_t)bx * nthreads + tid;
+    if (j >= p.n) return;
+    T v[LCM_SRC];
+#pragma unroll
+    for (int u = 0; u < LCM_SRC; u++) v[u] = (u < p.nsrc) ? p.polys[(size_t)p.src[u] * p.stride + j] : (T)0;
+#pragma unroll
+    for (int o = 0; o < LCM_OUT; o++) {
+      if (o < p.nout) {
+        T acc = 0;
+#pragma unroll
+        for (int u = 0; u < LCM_SRC; u++)
+          if (u < p.nsrc && p.m[o][u] != 0) acc = F::add(acc, F::mul(p.m[o][u], v[u]));
+        p.dst[o][j] = acc;
+      }
+    }
+  }
+};
 template <class F> struct MixKernel {
   typedef typename F::T T;
   static constexpr int THREADS = mspoly::THREADS;

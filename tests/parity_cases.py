@@ -321,6 +321,54 @@ def case_lincomb_many_terms(mk_fresh, field, k, linear, log_n=5, blowup=4):
     assert (ctx.lde_read() == o.lde_read()).all()
 
 
+def case_lincomb_shared_sweep(mk_fresh, field, log_n=6, blowup=8):
+    """Seven linear constraint polynomials over a 10-column trace: the LDE stage computes their columns in shared sweeps
+    (LincombMultiKernel: up to 4 outputs over up to 8 distinct sources per launch) - groups that fill up on outputs, a group that fills up on
+    sources, a column named twice, a coefficient 1, and one polynomial whose source is itself a linear column (must keep its order).
+    Polynomials, LDE matrix and root against the oracle; MS_LDE_MULTI=0 (one launch per column) must give the same bytes."""
+    import os
+    p = MODULUS[field]
+    N = 1 << log_n
+    w = 10
+    trace = rand_field(field, (N, w), seed=4242)
+    rng = SplitMix64(77)
+    combos = [
+        ([rng.nonzero(p), rng.nonzero(p)], [0, 1]),
+        ([1, rng.nonzero(p), rng.nonzero(p)], [1, 2, 1]),                 # column 1 twice, coefficient 1
+        ([rng.nonzero(p)] * 3, [3, 4, 5]),
+        ([rng.nonzero(p), p - 1], [6, 7]),                                # the fourth output: sources 0..7 = 8 distinct, group full
+        ([rng.nonzero(p), rng.nonzero(p)], [8, 9]),                       # does not fit the sources any more: new group
+        ([rng.nonzero(p), rng.nonzero(p)], [w + 1, 2]),                   # a source that is a linear column
+        ([rng.nonzero(p) for _ in range(8)], [0, 2, 4, 6, 8, 1, 3, 5]),   # eight distinct sources on its own
+    ]
+    outs = []
+    for multi in ("1", "0"):
+        old = os.environ.get("MS_LDE_MULTI")
+        os.environ["MS_LDE_MULTI"] = multi
+        try:
+            ctx = mk_fresh(field)
+        finally:
+            if old is None:
+                del os.environ["MS_LDE_MULTI"]
+            else:
+                os.environ["MS_LDE_MULTI"] = old
+        assert ctx.trace_commit(trace, w)[0] == 0 and ctx.interpolate() == 0
+        for sc, idx in combos:
+            assert ctx.polys_lincomb(sc, idx) == 0
+        r = ctx.lde_commit(blowup, 5, w + len(combos))
+        assert r[0] == 0
+        outs.append((r[1], ctx.lde_read()))
+    o = orc.Session(field)
+    assert o.trace_commit(trace, w)[0] == 0 and o.interpolate() == 0
+    for sc, idx in combos:
+        assert o.polys_lincomb(sc, idx) == 0
+    rb = o.lde_commit(blowup, 5, w + len(combos))
+    ref = o.lde_read()
+    for root, lde in outs:
+        assert root == rb[1]
+        assert (lde == ref).all()
+
+
 def case_device_trace_range_check(mk, field, to_device):
     """ms_trace_commit_device validates the canonical range on the device: a trace element >= p gives MS_ERR_ARG, like
     the host path; a clean trace gives the host path's root.  `to_device(np_u64_array) -> (pointer, keepalive)`."""

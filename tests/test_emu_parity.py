@@ -184,3 +184,8 @@ def test_ntt_register_last_pass(mk, monkeypatch, v2):
 def test_ntt_register_last_pass_full_tiles(mk):
     """The shipped shape: 2^10 x 2^10 x 2 on a 2^21-point transform (default knobs)."""
     pc.case_ntt(lambda f, fresh=False: mk(f, fresh=True), 0, 21, batch=1)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_lincomb_shared_sweep(mk, field):
+    pc.case_lincomb_shared_sweep(lambda f: mk(f, fresh=True), field)

@@ -384,3 +384,9 @@ def test_babybear_on_the_round2_tiles(mk, monkeypatch):
     fresh = lambda f, fresh=False: mk(f, fresh=True)
     pc.case_ntt(fresh, 1, 16)
     pc.case_coset_lde(fresh, 1, 14, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field", [0, 1])
+def test_lincomb_shared_sweep(mk, field):
+    pc.case_lincomb_shared_sweep(lambda f: mk(f, fresh=True), field, log_n=12)
