@@ -774,15 +774,15 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 // so a lane takes VEC neighbouring columns, loads their 2^K row elements (16-byte loads, fully coalesced), transforms, stores.  No LDS, no
 // twiddle tables for Goldilocks (radix <= 64 twiddles are shifts).  A streaming kernel: it lets a 2^21..2^25-point transform run as
 // 2^10 x 2^10 x 2^K (two passes on the large cooperative tiles + this copy-speed pass) instead of three passes of 2^8-row tiles.
-template <class F, class A, bool INV, int K> struct RegPassKernel {
-  typedef typename F::T T;
-  typedef PassParams<F> Params;
 #ifndef MS_REG_TH
 #define MS_REG_TH 128   // measured at 2^27 points x 6 columns: 64..128 threads 2.56-2.59 ms, 256 threads 2.98 ms, 512 threads 2.70 ms (8-byte accesses: 2.58-3.0 ms)
 #endif
 #ifndef MS_REG_VECMAXK
 #define MS_REG_VECMAXK 4
 #endif
+template <class F, class A, bool INV, int K> struct RegPassKernel {
+  typedef typename F::T T;
+  typedef PassParams<F> Params;
   static constexpr int THREADS = MS_REG_TH;
   static constexpr int R = 1 << K;
   static constexpr int VEC = (K <= MS_REG_VECMAXK) ? 16 / (int)sizeof(T) : 1;     // 2^K * VEC elements per lane stay in registers
