@@ -504,7 +504,8 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
   }
 
   // one sub-round: digit of B bits at row bits [SLO, SLO + B); item g = the other row bits (hi:lo packed), c = column
-  template <int SR, int J> static MS_DEV void sub_items(int tid, T* tile, const T* w) {
+  // MG: `w` is this boundary's merged per-tile table [2^B][Q] (sub-round twiddle x the row-twiddle factor of this output digit) instead of w_r
+  template <int SR, int J, bool MG = false> static MS_DEV void sub_items(int tid, T* tile, const T* w) {
     constexpr int B = DG::bits(SR), SLO = DG::slo(SR), Q = 1 << SLO;
     constexpr int ITEMS = (R >> B) * C, NJ = (ITEMS + TH - 1) / TH;
     constexpr bool LAST = (SR == NSUB - 1);
@@ -525,11 +526,11 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #pragma unroll
       for (int e = 0; e < (1 << B); e++) {
         T v = x[bitrev(e, B)];
-        if constexpr (!LAST) { if (e != 0) v = A::mul_tw(v, w[(e * lo) << (K - SLO - B)]); }   // w_{Q 2^B}^(e * lo); lo == 0 multiplies by w[0] = 1
+        if constexpr (!LAST) { if (e != 0) v = A::mul_tw(v, MG ? w[(e << SLO) + lo] : w[(e * lo) << (K - SLO - B)]); }   // w_{Q 2^B}^(e * lo); lo == 0 multiplies by w[0] = 1
         base[e & 3][(SLO == 0 ? (e & ~3) : e * Q) * C] = v;
       }
     }
-    if constexpr (J + 1 < NJ) sub_items<SR, J + 1>(tid, tile, w);
+    if constexpr (J + 1 < NJ) sub_items<SR, J + 1, MG>(tid, tile, w);
   }
 
   // ---- cooperative, persistent form: a workgroup walks tiles g = bx, bx + nbx, ... of the nbatch * tiles of the launch, and the
@@ -549,6 +550,9 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #endif
 #ifndef MS_NTT_STAGE_SRC
 #define MS_NTT_STAGE_SRC 1
+#endif
+#ifndef MS_NTT_MERGE_TW
+#define MS_NTT_MERGE_TW 1
 #endif
 #ifndef MS_NTT_VLOAD_UNROLL
 #define MS_NTT_VLOAD_UNROLL 4   // coefficient + twiddle gathers in flight per thread in the load of the pass behind the virtual pass
@@ -608,7 +612,18 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     const size_t stride = xcd_map ? (size_t)(nbx >> 3) : (size_t)nbx, first = xcd_map ? (size_t)(bx >> 3) : (size_t)bx;
     const size_t lim = xcd_map ? (total >> 3) : total, base_g = xcd_map ? (size_t)(bx & 7) * (total >> 3) : 0;
     if (first >= lim) return;
-    for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
+    // Behind the virtual pass an element meets five twiddles: the virtual pass's at the load, two sub-round boundaries, and at the store
+    // w_n^(8 k2 i_new) (row) and w_n^(k2 i1) (column).  i_new = E0 + 2^B0 E1 + 2^(B0+B1) E2 (one output digit per sub-round), so the row
+    // twiddle is a product of one factor per digit: the factors of E0 and E1 ride on the boundary tables (per tile: tb0[E0][lo] in the w
+    // region, tb1[E1][lo] in the row-twiddle region) and the factor of the last digit is merged with the column twiddle into ts[E_last][i1]
+    // - FOUR multiplications per element instead of five (154 -> 137 VALU instructions per element).  All factors are exact field elements,
+    // so the regrouping does not change a bit of the result.
+    constexpr bool MERGE = MODE == 2 && !PREFETCH && MS_NTT_MERGE_TW && F::ID == 0;   // Goldilocks only: BabyBear's butterflies read w_r inside the sub-rounds, so its w region cannot be given away
+    constexpr int B0 = DG::bits(0), Q0 = 1 << DG::slo(0), B1 = DG::bits(1), Q1 = 1 << DG::slo(1);
+    constexpr int NTB1 = NSUB == 3 ? (R >> B0) : 0;          // entries of tb1 (none with two sub-rounds: the second one is the last)
+    static_assert(!MERGE || NTB1 + (1 << BL) * C <= R, "merged tables must fit the row-twiddle region");
+    T* tb1 = twr; T* ts = twr + NTB1;
+    if (!MERGE) for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
     V16 rows[NROWS]; T xs[NXS];
     size_t tl, by;
     locate(base_g + first, tiles, &tl, &by);
@@ -674,6 +689,15 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
             for (int j = 0; j < NS; j++) { const int row = tid + j * TH; if (row < R) twr[row] = sv[j]; }
             msrt::wg_barrier();
           }
+          if constexpr (MERGE) {   // tb0[E0][lo] = w_r^(E0 lo) * w_n^(X E0), X = k_low * Rp (the previous tile's last reader is behind the end-of-tile barrier)
+            const size_t X = (f0 >> p.log_Rp) << p.log_Rp;
+            for (int idx = tid; idx < R; idx += TH) {
+              const int e = idx >> DG::slo(0), lo = idx & (Q0 - 1);
+              T v = p.w_r[e * lo];
+              if (X && e) v = A::mul_tw(v, tw_global(p, X * (size_t)e));
+              w[idx] = v;
+            }
+          }
 #pragma unroll MS_NTT_VLOAD_UNROLL
           for (int idx = tid; idx < R * C; idx += TH) {
             const int row = idx >> LC, i1 = idx & (C - 1);
@@ -693,7 +717,23 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         }
       }
       msrt::wg_barrier();
-      if (row_tw && STAGE) {   // the staged coefficients have been consumed: the region takes the row twiddles (read in the store phase)
+      if constexpr (MERGE) {   // the staged coefficients have been consumed: the region takes tb1 (read after the next barrier) and ts (read in the store phase)
+        const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
+        for (int idx = tid; idx < NTB1 + (1 << BL) * C; idx += TH) {
+          T v;
+          if (idx < NTB1) {
+            const int e = idx >> DG::slo(1), lo = idx & (Q1 - 1);
+            v = p.w_r[(e * lo) << B0];                                        // w_(Q1 2^B1)^(e lo)
+            if (X && e) v = A::mul_tw(v, tw_global(p, (X * (size_t)e) << B0));
+            tb1[idx] = v;
+          } else {
+            const int j = idx - NTB1, e = j >> LC, c = j & (C - 1);           // last digit x column
+            v = tw_global(p, (X * (size_t)e) << (K - BL));
+            if (k_low && c) v = A::mul_tw(v, tw_global(p, k_low * (size_t)c));
+            ts[j] = v;
+          }
+        }
+      } else if (row_tw && STAGE) {   // the staged coefficients have been consumed: the region takes the row twiddles (read in the store phase)
         const size_t k_low = f0 >> p.log_Rp;
         for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);
       }
@@ -703,7 +743,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         stage_issue(ntl, nby);
       }
 #ifndef MS_ABL_NOCOMPUTE   // ablation builds (tools/ntt_ablate.sh): memory-only / compute-only timings of the same kernel
-      sub_items<0, 0>(tid, tile, w);
+      sub_items<0, 0, MERGE>(tid, tile, w);
 #endif
       msrt::wg_barrier();
       if (PREFETCH && it + stride < lim) {   // next tile's loads: in flight during the remaining sub-rounds and the store
@@ -712,7 +752,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         prefetch(p, ntl, nby, tid, rows, xs);
       }
 #ifndef MS_ABL_NOCOMPUTE
-      sub_items<1, 0>(tid, tile, w);
+      if constexpr (MERGE && NSUB == 3) sub_items<1, 0, true>(tid, tile, tb1); else sub_items<1, 0>(tid, tile, w);
 #endif
       msrt::wg_barrier();
 #ifndef MS_ABL_NOCOMPUTE
@@ -725,7 +765,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         const size_t k_low = f0 >> p.log_Rp, i_done0 = (f0 & (((size_t)1 << p.log_Rp) - 1)) + c0;
         T* out = dst + ((k_low << p.log_Rp) << K) + i_done0;
         T gc[VEC];                                     // behind the virtual pass: w_n^(k_low * i_done), i_done = the column
-        const bool col_tw = row_tw && MODE == 2;
+        const bool col_tw = row_tw && MODE == 2 && !MERGE;
 #pragma unroll
         for (int v = 0; v < VEC; v++) gc[v] = col_tw ? tw_global(p, k_low * (size_t)(c0 + v)) : F::to_tw(F::from_u64(1));
 #pragma unroll 2
@@ -733,11 +773,12 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
           const int row = rb + i * RPS;
           const int inew = row_to_inew(row);
           V16 o = *reinterpret_cast<const V16*>(tile + tix(row, c0));
-          const T rt = row_tw ? twr[row] : F::to_tw(F::from_u64(1));
+          const T rt = (row_tw && !MERGE) ? twr[row] : F::to_tw(F::from_u64(1));
 #pragma unroll
           for (int v = 0; v < VEC; v++) {
             T x = o[v];
-            if (row_tw) x = A::mul_tw(x, rt);
+            if constexpr (MERGE) { if (row_tw) x = A::mul_tw(x, ts[((row & ((1 << BL) - 1)) << LC) + c0 + v]); }   // last digit's row factor x column twiddle
+            else if (row_tw) x = A::mul_tw(x, rt);
             if (col_tw && (c0 + v)) x = A::mul_tw(x, gc[v]);
             if (do_scale) x = A::mul_tw(x, p.scale);
             o[v] = x;
