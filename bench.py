@@ -72,8 +72,6 @@ class Lanes:
             self.d_traces = [torch.from_numpy(t.data.view(np.int64)).to(dev) for t in self.tts]  # resident in HBM before the timed region
         torch.cuda.synchronize()
         self.last = [None] * inflight
-        if os.environ.get("MS_BENCH_DUMP_MAPS"):   # debugging aid: the address map of this process (to resolve a crash's raw frames)
-            open(os.environ["MS_BENCH_DUMP_MAPS"], "w").write(open("/proc/self/maps").read())
 
     def _prove_n(self, i, n):
         ptr = None if self.io else self.d_traces[i].data_ptr()
