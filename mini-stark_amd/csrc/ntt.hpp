@@ -619,10 +619,10 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     // - FOUR multiplications per element instead of five (154 -> 137 VALU instructions per element).  All factors are exact field elements,
     // so the regrouping does not change a bit of the result.
     constexpr bool MERGE = MODE == 2 && !PREFETCH && MS_NTT_MERGE_TW && F::ID == 0;   // Goldilocks only: BabyBear's butterflies read w_r inside the sub-rounds, so its w region cannot be given away
-    constexpr int B0 = DG::bits(0), Q0 = 1 << DG::slo(0), B1 = DG::bits(1), Q1 = 1 << DG::slo(1);
+    [[maybe_unused]] constexpr int B0 = DG::bits(0), Q0 = 1 << DG::slo(0), Q1 = 1 << DG::slo(1);
     constexpr int NTB1 = NSUB == 3 ? (R >> B0) : 0;          // entries of tb1 (none with two sub-rounds: the second one is the last)
     static_assert(!MERGE || NTB1 + (1 << BL) * C <= R, "merged tables must fit the row-twiddle region");
-    T* tb1 = twr; T* ts = twr + NTB1;
+    [[maybe_unused]] T* tb1 = twr; [[maybe_unused]] T* ts = twr + NTB1;
     if (!MERGE) for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
     V16 rows[NROWS]; T xs[NXS];
     size_t tl, by;
