@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line.  Besides the headline it carries
   roofline_valu  the SHA-256 kernels (59 % of the kernel time) against the VALU issue roofline
   sharded        N > 1 only: ONE 2^24-row proof (BASELINE configs[3]) computed by all ranks together (ms_set_shard_rccl:
                  coset-partitioned LDE/FRI + leaf hashing, RCCL digest all-to-all + root all-gather inside the library;
-                 strong scaling), under a watchdog so that a failure there cannot take the headline down
+                 strong scaling), in a child process per rank so that neither a hang nor a crash there can take the headline down
   extra          N == 1 only: 2^24-row Goldilocks and 2^20-row BabyBear+Fp4 proofs/s, NTT-only GB/s at 2^20 and 2^24 rows,
                  and `value_with_io` (trace from pinned host memory, FRI proof read back, overlapped over the in-flight lanes)
   cpu_baseline   N == 1 only: the CPU oracle ("port") on the same 2^20-row proof, 1 thread and OpenMP
@@ -223,30 +223,36 @@ def main():
                    "proofs_per_step_per_gpu": C_IN, "parallelism": f"replicas x{world} GPUs x {C_IN} in-flight proofs (no data-path collective)"},
     }
 
-    # ---- N > 1: the sharded proof of BASELINE configs[3] as a second leg, behind a watchdog
+    # ---- N > 1: the sharded proof of BASELINE configs[3] as a second leg.  It runs in a CHILD process per rank (this script in --mode shard,
+    # its own rendezvous on MASTER_PORT + 1): the RCCL path inside the library has never run on more than one GPU, and neither a hang
+    # (subprocess timeout) nor a crash of it may take the headline down.
     if world > 1 and not args.no_shard_leg:
+        import subprocess
         lanes.close()
         lanes = None
-        done = threading.Event()
-        if rank == 0:   # stderr only (stdout carries exactly one JSON line): the headline survives in the log even if the next leg takes the process down
-            print(f"[bench] replicas leg done: {out['value']:.2f} proofs/s on {world} GPUs; starting the sharded leg", file=sys.stderr, flush=True)
-
-        def watchdog():
-            if not done.wait(args.shard_timeout):
-                if rank == 0:
-                    out["sharded"] = {"error": f"the sharded leg did not finish within {args.shard_timeout:.0f} s; headline unaffected"}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
+        torch.cuda.empty_cache()
+        if rank == 0:   # stderr only (stdout carries exactly one JSON line)
+            print(f"[bench] replicas leg done: {out['value']:.2f} proofs/s on {world} GPUs; starting the sharded leg in child processes", file=sys.stderr, flush=True)
+        grp.barrier()
+        env = dict(os.environ)
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # torchrun's workers use the agent's store on MASTER_PORT; the children host their own on the next port
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--mode", "shard", "--log-rows", str(args.shard_log_rows), "--steps", str(args.shard_steps),
+               "--warmup", "1", "--backend", args.backend, "--field", str(args.field), "--blowup", str(args.blowup), "--no-cpu-baseline", "--no-extras"]
         try:
-            res, _ = sharded_leg(args, grp, local_rank, args.shard_log_rows, args.shard_steps, 1)
-            out["sharded"] = res
-        except Exception as e:  # noqa: BLE001 - reported in the JSON line; the other ranks are released by their watchdogs
-            out["sharded"] = {"error": f"{type(e).__name__}: {e}"}
+            cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.shard_timeout)
+            lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
             if rank == 0:
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        done.set()
+                if cp.returncode == 0 and lines:
+                    out["sharded"] = json.loads(lines[-1])["exchange"]
+                else:
+                    out["sharded"] = {"error": f"sharded leg exited with code {cp.returncode}; headline unaffected", "stderr_tail": cp.stderr[-600:]}
+        except subprocess.TimeoutExpired:
+            if rank == 0:
+                out["sharded"] = {"error": f"the sharded leg did not finish within {args.shard_timeout:.0f} s; headline unaffected"}
+        except Exception as e:  # noqa: BLE001 - reported in the JSON line
+            if rank == 0:
+                out["sharded"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         if lanes is None:
