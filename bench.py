@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--shard-log-rows", type=int, default=24, help="size of the sharded leg's proof (BASELINE configs[3]: 24)")
     ap.add_argument("--shard-steps", type=int, default=3)
     ap.add_argument("--no-shard-leg", action="store_true")
-    ap.add_argument("--shard-timeout", type=float, default=420.0, help="watchdog for the sharded leg (seconds)")
+    ap.add_argument("--shard-timeout", type=float, default=240.0, help="time limit of the sharded leg's child processes (seconds)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL, one GPU per rank (the measured configuration).  gloo: rehearsal of the N>1 paths on a box with fewer GPUs than ranks "
                          "(ranks share GPUs, exchange payloads are staged through host memory)")
