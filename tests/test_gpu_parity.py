@@ -35,6 +35,13 @@ def test_ntt(mk, field, log_n):
     pc.case_ntt(mk, field, log_n, batch=2 if log_n < 19 else 1)
 
 
+@pytest.mark.parametrize("log_n", [14, 15, 16, 18, 19, 21])
+def test_coset_lde_tile_shapes(mk, log_n):
+    """Blowup-8 Goldilocks LDEs whose plans walk every tile shape of the cooperative passes behind the virtual pass
+    (2^7 x 2^7, 2^8 x 2^7, 2^8 x 2^8, 2^9 x 2^9, 2^10 x 2^9) and the register-only last pass (2^10 x 2^10 x 2)."""
+    pc.case_coset_lde(mk, 0, log_n, 8)
+
+
 @pytest.mark.parametrize("field,log_n", [(0, 23), (0, 24), (1, 23)])
 def test_ntt_large_vs_oracle(mk, field, log_n):
     pc.case_ntt(mk, field, log_n, batch=1)
