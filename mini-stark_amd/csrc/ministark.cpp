@@ -295,6 +295,7 @@ template <class F> struct Ctx : CtxBase {
   DevBuf ntt_scratch;
   int ntt_kmax = 9;            // largest tile (log2 rows) of a multi-pass plan; MS_NTT_KMAX overrides (tuning)
   int ntt_v2 = 1, ntt_v2_min = 14, ntt_v2_maxpass = 2, ntt_v2_sub3 = 1, ntt_v2_wide = 0, ntt_v2_regpass = 1;   // MS_NTT_V2=0: round-1 kernels only (A/B); transforms of at least 2^MS_NTT_V2_MIN points use the two-sub-round tiles
+  int ntt_colbatch = 0, ntt_mall_mib = 96;    // MS_NTT_COLBATCH: columns per chunk of a multi-pass transform (0: all; -1: as many as keep a chunk within MS_NTT_MALL_MIB); see ntt_run
   int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1, ntt_fast = 1, ntt_fast_min = 22, ntt_fast_max = 24;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
 
   // log_pad: the input is zero beyond n >> log_pad
@@ -533,15 +534,29 @@ template <class F> struct Ctx : CtxBase {
       if (ntt_scratch.ensure(batch * n * sizeof(T))) return fail(MS_ERR_NOMEM, "ntt scratch");
       scr = ntt_scratch.as<T>();
     }
-    const T* in = src; size_t in_bs = src_bstride;
+    // Column chunks (MS_NTT_COLBATCH = columns per chunk; 0 = the default: all columns per launch; -1: as many as fit MS_NTT_MALL_MIB):
+    // the passes of a multi-pass plan run chunk by chunk, so that what one pass writes is still in the 256 MiB Infinity Cache when the
+    // next pass reads it back.  Measured (r02, profiles/r02_stride_probe.log, r02_colbatch.log): the later pass's access PATTERN alone
+    // takes 24.5 us per resident 64 MiB column against 47.7 us when six columns are swept per launch - but the complete kernel takes
+    // 45 us per column either way (a one-column launch is no faster than a third of a three-column one): the pass is bound by exposed
+    // latency at 4 waves per SIMD, not by HBM or by the pattern, so chunking buys nothing (LDE 6 x 2^20: 0.641 ms chunked, 0.627 not).
+    size_t chunk = batch;
+    if (P >= 2 && batch > 1) {
+      if (ntt_colbatch > 0) chunk = (size_t)ntt_colbatch;
+      else if (ntt_colbatch < 0) { const size_t col = n * sizeof(T), budget = (size_t)ntt_mall_mib << 20; chunk = col >= budget ? (col <= ((size_t)128 << 20) ? 1 : batch) : budget / col; }
+      if (chunk < 1 || chunk > batch) chunk = batch;
+    }
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+    const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+    const T* in = src + b0 * src_bstride; size_t in_bs = src_bstride;
     int log_Rp = log_r0;
     for (int k = 0; k < P; k++) {
       T* out; size_t out_bs;
-      if (k == P - 1) { out = dst; out_bs = dst_bstride; }
+      if (k == P - 1) { out = dst + b0 * dst_bstride; out_bs = dst_bstride; }
       else {
         const bool even = ((P - 1 - (k + 1)) % 2 == 0);
         const bool to_dst = last_inplace ? even : !even;
-        out = to_dst ? dst : scr; out_bs = to_dst ? dst_bstride : n;
+        out = to_dst ? dst + b0 * dst_bstride : scr + b0 * n; out_bs = to_dst ? dst_bstride : n;
       }
       msntt::PassParams<F> pp;
       pp.src = in; pp.dst = out; pp.src_bstride = in_bs; pp.dst_bstride = out_bs;
@@ -554,12 +569,13 @@ template <class F> struct Ctx : CtxBase {
       pp.log_r0 = (k == 0) ? log_r0 : 0; pp.log_rho = (k == 0) ? pl->log_rho : 0;
       const int cols_log = log_n - pl->K[k];
       pp.log_C = cols_log < pl->LC[k] ? cols_log : pl->LC[k];
-      pp.last = (k == P - 1); pp.nbatch = (u32)batch;
+      pp.last = (k == P - 1); pp.nbatch = (u32)nb;
       const size_t tiles = ((size_t)1 << cols_log) >> pp.log_C;
-      next_bytes = (double)(n_in + n) * batch * sizeof(T) / P;  // (n_in + n)*s per transform, shared by its P real passes
-      if (inverse) CK(launch_pass<true>(pp, tiles, batch, pl->v2[k], pl->regp[k])); else CK(launch_pass<false>(pp, tiles, batch, pl->v2[k], pl->regp[k]));
+      next_bytes = (double)(n_in + n) * nb * sizeof(T) / P;  // (n_in + n)*s per transform, shared by its P real passes
+      if (inverse) CK(launch_pass<true>(pp, tiles, nb, pl->v2[k], pl->regp[k])); else CK(launch_pass<false>(pp, tiles, nb, pl->v2[k], pl->regp[k]));
       in = out; in_bs = out_bs;
       log_Rp += pl->K[k];
+    }
     }
     return 0;
   }
@@ -733,6 +749,8 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_V2_REGPASS")) ntt_v2_regpass = atoi(e);
     if (const char* e = getenv("MS_NTT_COOP_WGS")) { int v = atoi(e); if (v >= 8 && v <= 65536) ntt_coop_wgs = v & ~7; }
     if (const char* e = getenv("MS_NTT_V2_MAXPASS")) { int v = atoi(e); if (v >= 1 && v <= 4) ntt_v2_maxpass = v; }
+    if (const char* e = getenv("MS_NTT_COLBATCH")) ntt_colbatch = atoi(e);
+    if (const char* e = getenv("MS_NTT_MALL_MIB")) { int v = atoi(e); if (v >= 1) ntt_mall_mib = v; }
     if (const char* e = getenv("MS_NTT_V2_MIN")) { int v = atoi(e); if (v >= 12 && v <= 32) ntt_v2_min = v; }
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
     if (const char* e = getenv("MS_LDE_MULTI")) lde_multi = atoi(e);
