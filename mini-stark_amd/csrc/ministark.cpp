@@ -417,6 +417,9 @@ template <class F> struct Ctx : CtxBase {
     next_sub = K | (TH == 512 ? 16 : 0) | (INV ? 64 : 0);
     return run<KK>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, TH, KK::lds_bytes(), pp);
   }
+#ifndef MS_ARITH3
+#define MS_ARITH3 GLM   // arithmetic class of the 512-thread three-sub-round tiles (A/B builds: -DMS_ARITH3=GLT)
+#endif
   template <bool INV, int K, int LC, int MODE>
   int launch_v2m(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
     if constexpr (F::ID == 0 && K == 10 && LC == 4 && MODE == 1) {   // 16 columns x 1024 rows: 1024 threads, one workgroup per CU
@@ -436,7 +439,7 @@ template <class F> struct Ctx : CtxBase {
     }
     if constexpr (F::ID == 0 && K == 10 && LC == 3) {
       if (ntt_v2_sub3) {   // 512 threads, three sub-rounds, exec-masked arithmetic: 16 waves per CU
-        typedef msntt::PassKernel2<F, GLM, INV, K, LC, 512, 3, MODE> KK;
+        typedef msntt::PassKernel2<F, MS_ARITH3, INV, K, LC, 512, 3, MODE> KK;
         if (!KK::applicable(pp)) return 998;
         next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | 2048 | (MODE << 12);
         return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch), 512, KK::lds_bytes(), pp);

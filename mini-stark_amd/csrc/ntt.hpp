@@ -558,6 +558,40 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #define MS_NTT_VLOAD_UNROLL 4   // coefficient + twiddle gathers in flight per thread in the load of the pass behind the virtual pass
 #endif
   static constexpr bool PREFETCH = MS_NTT_PREFETCH != 0;
+  // Fused tail (r02): the last sub-round's lanes take TWO neighbouring columns of their 2^BL rows, so that what they hold after the
+  // butterflies is exactly the 16-byte pieces of the store - no write-back of the last sub-round, no read-back for the store, one
+  // barrier less per tile (measured, 6-column launches: first pass 327.5 -> 313.2 us, later pass 266.6 -> 258.0 us).
+  // MS_NTT_DMA=1 (off): later passes fetch the NEXT tile by LDS-DMA (global_load_lds_dwordx4, no registers) as soon as the last sub-round
+  // has its inputs in registers, so that the loads are in flight during its arithmetic and the store, and wait for them with a counted
+  // vmcnt that leaves the tile's own stores in flight.  Bit-exact (CPU emulation and GPU suite), but no faster: 265 us against 258 -
+  // like a column resident in the Infinity Cache (MS_NTT_COLBATCH), hiding the memory side changes nothing, because these passes are
+  // bound by the CU's instruction issue: per 1536 executed VALU instructions a thread issues ~1180 scalar ones for the exec-masked
+  // corrections plus 670 s_nop wait states (disassembly of the later pass), and a second workgroup per CU buys 1.37x, not 2x.
+#ifndef MS_NTT_FUSE_TAIL
+#define MS_NTT_FUSE_TAIL 1
+#endif
+#ifndef MS_NTT_DMA
+#define MS_NTT_DMA 0
+#endif
+#ifndef MS_NTT_DMA_COUNTED
+#define MS_NTT_DMA_COUNTED 1
+#endif
+  static constexpr int TAIL_ITEMS = (R >> BL) * LPR, NJT = (TAIL_ITEMS + TH - 1) / TH;
+  static constexpr bool FUSE_TAIL = MS_NTT_FUSE_TAIL != 0 && MODE != 0 && NSUB == 3 && TAIL_ITEMS % TH == 0 && !PREFETCH;
+  static constexpr int DMA_ROWS = 1024 / (C * (int)sizeof(T)), DMA_INST = R / DMA_ROWS / (TH / 64);   // rows per wave instruction (1 KiB), instructions per wave and tile
+  static constexpr bool DMA = MS_NTT_DMA != 0 && FUSE_TAIL && MODE == 1 && (C * (int)sizeof(T)) == 64 && R % (DMA_ROWS * (TH / 64)) == 0;
+  // LDS slot s of the swizzled tile holds row s ^ ((s >> BL) & 3) (prow is an involution): the swizzle goes on the SOURCE address, the wave's
+  // 64 lanes write 16 consecutive 64-byte slots
+  static MS_DEV void dma_issue(const Params& p, size_t tile_, size_t by_, int tid, T* tile) {
+    const size_t cs = ((size_t)1 << p.log_n) >> K;
+    const T* src = p.src + by_ * p.src_bstride + (tile_ << LC);
+    const int wave = tid >> 6, lane = tid & 63, q = lane % LPR;
+#pragma unroll
+    for (int i = 0; i < DMA_INST; i++) {
+      const int slot0 = (wave * DMA_INST + i) * DMA_ROWS, sl = slot0 + lane / LPR, row = sl ^ ((sl >> BL) & 3);
+      msrt::glds16(src + q * VEC + (size_t)row * cs, tile + (size_t)slot0 * C, lane);
+    }
+  }
   static constexpr int NROWS = (MODE == 2) ? 1 : SWEEPS, NXS = (MODE == 2) ? (R * C / TH) : 1;   // prefetch registers: whole 16-byte row pieces or, behind the virtual pass, single coefficients
   static MS_DEV void locate(size_t g, size_t tiles, size_t* tile, size_t* by) { *by = g / tiles; *tile = g - *by * tiles; }
   // issues the global loads of one work item into the caller's registers (fully unrolled: `rows` / `xs` never leave the register file)
@@ -644,9 +678,10 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       }
     };
     if (STAGE) stage_issue(tl, by);
+    if constexpr (DMA) dma_issue(p, tl, by, tid, tile);
     for (size_t it = first; it < lim; it += stride) {
       locate(base_g + it, tiles, &tl, &by);
-      if (!PREFETCH && MODE != 2) prefetch(p, tl, by, tid, rows, xs);
+      if (!PREFETCH && MODE != 2 && !DMA) prefetch(p, tl, by, tid, rows, xs);
       const size_t f0 = tl << LC;
       const bool row_tw = MODE != 0 && !p.last && (f0 >> p.log_Rp) != 0;
       // ---- the prefetched inputs go to LDS (behind the virtual pass: times w_(r0 r)^(i1 * row)); the row twiddles of this tile
@@ -667,7 +702,8 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         const size_t k_low = f0 >> p.log_Rp;
         for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);   // w_n^(k_low * Rp * i_new)
       }
-      if constexpr (MODE != 2) {
+      if constexpr (DMA) {}   // the tile was fetched by LDS-DMA (issued in the previous tile's tail, or before the loop)
+      else if constexpr (MODE != 2) {
 #pragma unroll
         for (int i = 0; i < SWEEPS; i++) *reinterpret_cast<V16*>(tile + tix(rb + i * RPS, c0)) = rows[i];
       } else {
@@ -716,7 +752,11 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
           }
         }
       }
-      msrt::wg_barrier();
+      if constexpr (DMA) {
+        // this tile's copies were issued before the previous tile's NJT << BL store instructions (nothing else touches vector memory in between
+        // when the pass has no row twiddles): wait for the copies, not for the acknowledgement of those stores
+        if (MS_NTT_DMA_COUNTED && p.last && it != first) msrt::wg_barrier_vm_but<(NJT << BL)>(); else msrt::wg_barrier_vm();
+      } else msrt::wg_barrier();
       if constexpr (MERGE) {   // the staged coefficients have been consumed: the region takes tb1 (read after the next barrier) and ts (read in the store phase)
         const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
         for (int idx = tid; idx < NTB1 + (1 << BL) * C; idx += TH) {
@@ -755,11 +795,60 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       if constexpr (MERGE && NSUB == 3) sub_items<1, 0, true>(tid, tile, tb1); else sub_items<1, 0>(tid, tile, w);
 #endif
       msrt::wg_barrier();
+      T* dst = p.dst + by * p.dst_bstride;
+      if constexpr (FUSE_TAIL) {
+        // ---- last sub-round + store, fused: item = (row group g of 2^BL rows, column pair cp); the rows of a group are the last digit
+        // E2 = 0 .. 2^BL - 1 of the output index, i_new = E0 + 2^B0 E1 + 2^(B0+B1) E2 with (E0, E1) = the digits of g
+        constexpr int NE = 1 << BL, B0_ = DG::bits(0), B1_ = DG::bits(1);
+        const size_t k_low = f0 >> p.log_Rp;
+        T* outb = dst + ((k_low << p.log_Rp) << K) + (f0 & (((size_t)1 << p.log_Rp) - 1));
+        const bool col_tw = row_tw && MODE == 2 && !MERGE;
+        V16 o[NJT][NE];
+#pragma unroll
+        for (int J = 0; J < NJT; J++) {
+          const int itq = tid + J * TH, cq = (itq % LPR) * VEC, g = itq / LPR, R0 = g << BL, h3 = g & 3;
+#pragma unroll
+          for (int e = 0; e < NE; e++) o[J][e] = *reinterpret_cast<const V16*>(tile + (size_t)(R0 + (e & ~3) + ((e & 3) ^ h3)) * C + cq);
+        }
+        if constexpr (DMA) {
+          msrt::wg_barrier();                        // every lane has its inputs: the tile buffer is free
+          if (it + stride < lim) { size_t ntl, nby; locate(base_g + it + stride, tiles, &ntl, &nby); dma_issue(p, ntl, nby, tid, tile); }
+        }
+#pragma unroll
+        for (int J = 0; J < NJT; J++) {
+          const int itq = tid + J * TH, cq = (itq % LPR) * VEC, g = itq / LPR, R0 = g << BL;
+          const int inew0 = (g >> B1_) | ((g & ((1 << B1_) - 1)) << B0_);
+          T gc[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; v++) gc[v] = col_tw ? tw_global(p, k_low * (size_t)(cq + v)) : F::to_tw(F::from_u64(1));
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            T x[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) x[e] = o[J][e][v];
+#ifndef MS_ABL_NOCOMPUTE
+            dif_regs<A, INV, BL>(x, w, K);
+#endif
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+              T y = x[bitrev(e, BL)];
+              if constexpr (MERGE) { if (row_tw) y = A::mul_tw(y, ts[(e << LC) + cq + v]); }   // last digit's row factor x column twiddle
+              else if (row_tw) y = A::mul_tw(y, twr[R0 + e]);
+              if (col_tw && (cq + v)) y = A::mul_tw(y, gc[v]);
+              if (do_scale) y = A::mul_tw(y, p.scale);
+              o[J][e][v] = y;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < NE; e++) *reinterpret_cast<V16*>(outb + cq + ((size_t)(inew0 | (e << (B0_ + B1_))) << p.log_Rp)) = o[J][e];
+        }
+        if (!DMA || !p.last) msrt::wg_barrier();     // the tile (no DMA) and the per-tile tables are free for the next work item
+        continue;
+      }
 #ifndef MS_ABL_NOCOMPUTE
       if constexpr (NSUB >= 3) { sub_items<2, 0>(tid, tile, w); msrt::wg_barrier(); }
 #endif
       // ---- store
-      T* dst = p.dst + by * p.dst_bstride;
       if constexpr (MODE != 0) {
         // out = k_low*Rp*r + i_done + Rp*i_new: a tile row is one 16*LPR-byte run
         const size_t k_low = f0 >> p.log_Rp, i_done0 = (f0 & (((size_t)1 << p.log_Rp) - 1)) + c0;

@@ -186,6 +186,17 @@ def test_ntt_register_last_pass_full_tiles(mk):
     pc.case_ntt(lambda f, fresh=False: mk(f, fresh=True), 0, 21, batch=1)
 
 
+def test_ntt_fused_tail_full_tiles(mk):
+    """The cooperative tiles whose last sub-round is fused with the store (and, in later passes, fed by LDS-DMA): 2^10 x 2^10 plain
+    (last later pass, no row twiddles), 2^16 / 2^17 coefficients behind the virtual pass (2^8-row tiles in both modes, 2^9 x 2^8), and
+    the benchmark's LDE shape 2^20 -> 2^23 (2^10-row tiles: merged twiddle tables in the first pass, DMA-fed last pass)."""
+    fresh = lambda f, fresh=False: mk(f, fresh=True)
+    pc.case_ntt(fresh, 0, 20, batch=1)
+    pc.case_coset_lde(fresh, 0, 16, 8)
+    pc.case_coset_lde(fresh, 0, 17, 8)
+    pc.case_coset_lde(fresh, 0, 20, 8)
+
+
 @pytest.mark.parametrize("field", [0, 1])
 def test_lincomb_shared_sweep(mk, field):
     pc.case_lincomb_shared_sweep(lambda f: mk(f, fresh=True), field)
