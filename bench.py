@@ -295,7 +295,7 @@ def main():
                            "variants": per_variant,
                            "all_ntt_pass_kernels": {"launches_per_proof": allp["launches"], "ms_per_proof": allp["ms"],
                                                     "alg_GBps": allp["alg_bytes"] / (allp["ms"] * 1e-3) / 1e9 if allp["ms"] else 0.0},
-                           "note": "pass kernels are bound by the NUMBER of VALU instructions (3.3-3.6 issue cycles each in integer code, tools/ntt_lab.hip), not by HBM (DESIGN.md 6.2)"}
+                           "note": "these passes are bound by the CU's instruction issue, not by HBM: 58-69 % of the VALU issue slots taken (one wave64 instruction per SIMD per 4 clocks), 0.6 scalar instructions per vector one for the exec-masked corrections; a column resident in the Infinity Cache or an LDS-DMA prefetch of the next tile changes nothing (DESIGN.md 6.2, profiles/r02_ntt_tail_dma_ab.log, r02_stride_probe.log)"}
         tot = sum(v["ms"] for v in prof.values()) or 1.0
         out["kernel_ms_per_proof"] = {n: round(v["ms"], 4) for n, v in prof.items() if v["launches"]}
         out["kernel_ms_total_single_proof"] = tot
@@ -321,7 +321,22 @@ def main():
                     rate = wi / (ms_cls * 1e-3)
                     rv[cls] = {"valu_wave_instr_per_proof": wi, "ms_per_proof": ms_cls, "achieved_wave_instr_per_s": rate,
                                "frac_of_guide_peak": rate / peak_guide, "frac_of_measured_issue_peak": rate / peak_meas}
-            out["roofline_valu"] = {"bound": "valu_issue", "unit": "wave-instr/s", "peak_guide": peak_guide, "peak_guide_basis": "MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op = 2 cycles, 2.4 GHz",
+            # the whole proof against the same peaks: every profiled kernel's VALU instructions x the headline rate (8 proofs in flight keep the VALU fed)
+            wi_all = wave_instr(("",))
+            peak_quad = N_SIMD * 2.2e9 / 4.0          # one wave64 instruction per SIMD per 4 clocks at the 2.2 GHz the chip holds under these kernels
+            big = [r for r in sq if r["kernel"].startswith("msmerkle::LeafHashKernel<GL; 1")]
+            big = max(big, key=lambda r: float(r["grid_threads"])) if big else None
+            rate_all = wi_all * (args.steps * C_IN / elapsed) if wi_all else 0.0
+            whole = {"valu_wave_instr_per_proof": wi_all, "achieved_wave_instr_per_s": rate_all, "frac_of_guide_peak": rate_all / peak_guide,
+                     "frac_of_measured_issue_peak": rate_all / peak_meas, "frac_of_quad_cycle_peak": rate_all / peak_quad,
+                     "note": "the profiled kernels' SQ_INSTS_VALU per proof x the headline proofs/s of THIS run (per GPU): the prover as a whole is bound by the number of VALU "
+                             "instructions it issues, 84 % of them SHA-256"}
+            if big:
+                r1 = float(big["grid_threads"]) / 64.0 * float(big["valu_wave_instr_per_thread"]) / (float(big["avg_us"]) * 1e-6)
+                whole["largest_leaf_launch"] = {"wave_instr_per_s": r1, "frac_of_quad_cycle_peak": r1 / peak_quad, "source": "profiles/" + sq_name + " (LDE leaf hashing: grid, instructions per thread and duration of the profiled run)"}
+            out["roofline_valu"] = {"bound": "valu_issue", "unit": "wave-instr/s", "peak_guide": peak_guide, "whole_proof": whole,
+                                    "peak_quad_cycle": peak_quad, "peak_quad_cycle_basis": "one wave64 VALU instruction per SIMD per 4 clocks, 1024 SIMDs, 2.2 GHz (the clock rocprofv3 GRBM_GUI_ACTIVE shows under the hash kernels): "
+                                    "the rate the large SHA-256 launches sustain (96 %) and nothing in this code base exceeds", "peak_guide_basis": "MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op = 2 cycles, 2.4 GHz",
                                     "peak_measured": peak_meas, "peak_measured_basis": "3.4 cycles per VALU instruction: what register-resident integer butterfly code sustains at >= 4 waves/SIMD whatever the opcode mix "
                                     "(tools/ntt_lab.hip, profiles/r02_ntt_lab.log); the per-opcode costs of tools/valu_rate.hip did not carry over to mixed code",
                                     "instr_source": "profiles/" + sq_name + " (rocprofv3 --pmc SQ_INSTS_VALU per dispatch; constants, not measured in this run)",

@@ -195,16 +195,23 @@ struct GLM : GL {
         : "=&v"(T0), "=&v"(M), "=&v"(T1), "=&s"(c) : "v"(lo(a)), "v"(hi(a)), "v"(lo(b)), "v"(hi(b)) : "vcc");
     // 128-bit (lo, hi) = T0 + M * 2^32 + T1 * 2^64 + c * 2^96;  r = lo - hi_hi, then + hi_lo * EPS
     u32 L1, H0, H1, R0, R1; u64 bm;
-    asm("s_nop 1\n\t"                               // c was written by the VALU instruction that ended the previous statement
+#ifdef MS_ABL_NONOP   // ablation (timing only: the carry chain breaks the VALU-writes-SGPR -> VALU-reads wait states): what the s_nop cost
+#define MS_NOP1 ""
+#define MS_NOP0 ""
+#else
+#define MS_NOP1 "s_nop 1\n\t"
+#define MS_NOP0 "s_nop 0\n\t"
+#endif
+    asm(MS_NOP1                                     // c was written by the VALU instruction that ended the previous statement
         "v_addc_co_u32 %2, vcc, %9, 0, %11\n\t"   // H1 = hi(T1) + c   (no wrap: the product is < 2^128)
         "v_add_co_u32 %0, vcc, %6, %7\n\t"        // L1 = hi(T0) + lo(M)
-        "s_nop 1\n\t"
+        MS_NOP1
         "v_addc_co_u32 %1, vcc, %10, %8, vcc\n\t" // H0 = lo(T1) + hi(M) + carry
-        "s_nop 1\n\t"
+        MS_NOP1
         "v_addc_co_u32 %2, vcc, %2, 0, vcc\n\t"   // H1 += carry
-        "s_nop 0\n\t"
+        MS_NOP0
         "v_sub_co_u32 %3, vcc, %12, %2\n\t"       // r = lo - H1
-        "s_nop 1\n\t"
+        MS_NOP1
         "v_subbrev_co_u32 %4, vcc, 0, %0, vcc\n\t"
         "s_mov_b64 %5, vcc"                       // borrow mask
         : "=&v"(L1), "=&v"(H0), "=&v"(H1), "=&v"(R0), "=&v"(R1), "=&s"(bm)
