@@ -31,4 +31,7 @@ for log_n in (15, 16, 17, 18, 19):
     pc.case_ntt(lambda f, fresh=False: mk(f, fresh=True), 0, log_n, batch=1)
 pc.case_coset_lde(lambda f, fresh=False: mk(f, fresh=True), 0, 15, 8)
 del os.environ["MS_NTT_V2_REGPASS"]
+# fused last sub-round + store: 2^8-row tiles in both modes (2^16 coefficients behind the virtual pass) and the 2^10-row tiles of a plain 2^20-point transform
+pc.case_coset_lde(lambda f, fresh=False: mk(f, fresh=True), 0, 16, 8)
+pc.case_ntt(lambda f, fresh=False: mk(f, fresh=True), 0, 20, batch=1)
 print("asan run complete")
