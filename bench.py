@@ -336,7 +336,7 @@ def main():
                 whole["largest_leaf_launch"] = {"wave_instr_per_s": r1, "frac_of_quad_cycle_peak": r1 / peak_quad, "source": "profiles/" + sq_name + " (LDE leaf hashing: grid, instructions per thread and duration of the profiled run)"}
             out["roofline_valu"] = {"bound": "valu_issue", "unit": "wave-instr/s", "peak_guide": peak_guide, "whole_proof": whole,
                                     "peak_quad_cycle": peak_quad, "peak_quad_cycle_basis": "one wave64 VALU instruction per SIMD per 4 clocks, 1024 SIMDs, 2.2 GHz (the clock rocprofv3 GRBM_GUI_ACTIVE shows under the hash kernels): "
-                                    "the rate the large SHA-256 launches sustain (96 %) and nothing in this code base exceeds", "peak_guide_basis": "MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op = 2 cycles, 2.4 GHz",
+                                    "the issue rate of the carry / 64-bit / rotate / multiply / v_add3 class (tools/valu_rate.hip; simple 32-bit operations issue at ~2.5 cycles) and the average the large SHA-256 launches reach (96 %)", "peak_guide_basis": "MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op = 2 cycles, 2.4 GHz",
                                     "peak_measured": peak_meas, "peak_measured_basis": "3.4 cycles per VALU instruction: what register-resident integer butterfly code sustains at >= 4 waves/SIMD whatever the opcode mix "
                                     "(tools/ntt_lab.hip, profiles/r02_ntt_lab.log); the per-opcode costs of tools/valu_rate.hip did not carry over to mixed code",
                                     "instr_source": "profiles/" + sq_name + " (rocprofv3 --pmc SQ_INSTS_VALU per dispatch; constants, not measured in this run)",

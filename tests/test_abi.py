@@ -45,3 +45,17 @@ def test_host_library_exports_its_header():
     ctypes.CDLL(ms.build_library(), mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(build_host_library())
     assert not [s_ for s_ in syms if not hasattr(lib, s_)]
+
+
+def test_rust_ffi_block_matches_header():
+    """examples/rust_shim/src/ffi.rs (the reference-side binding; not compilable here: no cargo) declares exactly the functions
+    include/ministark.h declares - no symbol missing, none invented - and every stage method of the safe wrapper calls one of them."""
+    ffi = open(os.path.join(ROOT, "examples", "rust_shim", "src", "ffi.rs")).read()
+    rust = sorted(set(re.findall(r"pub fn (ms_[a-z0-9_]+)\s*\(", ffi)))
+    assert rust == declared_symbols()
+    lib = open(os.path.join(ROOT, "examples", "rust_shim", "src", "lib.rs")).read()
+    used = set(re.findall(r"\b(ms_[a-z0-9_]+)\s*\(", lib))
+    assert used and used <= set(rust)
+    for stage in ("ms_trace_commit", "ms_interpolate", "ms_polys_lincomb", "ms_lde_commit", "ms_mix", "ms_eval_ext", "ms_fri_begin", "ms_fri_deep",
+                  "ms_fri_fold_commit", "ms_fri_query", "ms_fri_proof_read"):
+        assert stage in used, stage
