@@ -334,7 +334,15 @@ def main():
             if big:
                 r1 = float(big["grid_threads"]) / 64.0 * float(big["valu_wave_instr_per_thread"]) / (float(big["avg_us"]) * 1e-6)
                 whole["largest_leaf_launch"] = {"wave_instr_per_s": r1, "frac_of_quad_cycle_peak": r1 / peak_quad, "source": "profiles/" + sq_name + " (LDE leaf hashing: grid, instructions per thread and duration of the profiled run)"}
-            out["roofline_valu"] = {"bound": "valu_issue", "unit": "wave-instr/s", "peak_guide": peak_guide, "whole_proof": whole,
+            peak_lab = N_SIMD * 2.2e9 / 3.65          # tools/sha_lab.hip (profiles/r02_sha_lab.log): the same compression code on registers only, 4-8 waves/SIMD: 3.5-3.8 clocks per instruction
+            for v in rv.values():
+                v["frac_of_sha_lab_rate"] = v["achieved_wave_instr_per_s"] / peak_lab
+            whole["frac_of_sha_lab_rate"] = rate_all / peak_lab
+            if big:
+                whole["largest_leaf_launch"]["frac_of_sha_lab_rate"] = whole["largest_leaf_launch"]["wave_instr_per_s"] / peak_lab
+            out["roofline_valu"] = {"bound": "valu_issue", "unit": "wave-instr/s", "peak_guide": peak_guide, "whole_proof": whole, "peak_sha_lab": peak_lab,
+                                    "peak_sha_lab_basis": "tools/sha_lab.hip: the compression function of csrc/merkle.hpp on register-resident data (no memory) issues one instruction per 3.5-3.8 clocks per SIMD at 4-8 waves "
+                                    "(28.5 G compressions/s chip-wide at 8 waves/SIMD, 26.4 at the leaf kernel's 4): the practical VALU ceiling of SHA-256 on this chip",
                                     "peak_quad_cycle": peak_quad, "peak_quad_cycle_basis": "one wave64 VALU instruction per SIMD per 4 clocks, 1024 SIMDs, 2.2 GHz (the clock rocprofv3 GRBM_GUI_ACTIVE shows under the hash kernels): "
                                     "the issue rate of the carry / 64-bit / rotate / multiply / v_add3 class (tools/valu_rate.hip; simple 32-bit operations issue at ~2.5 cycles) and the average the large SHA-256 launches reach (96 %)", "peak_guide_basis": "MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op = 2 cycles, 2.4 GHz",
                                     "peak_measured": peak_meas, "peak_measured_basis": "3.4 cycles per VALU instruction: what register-resident integer butterfly code sustains at >= 4 waves/SIMD whatever the opcode mix "
