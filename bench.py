@@ -75,8 +75,10 @@ class Lanes:
 
     def _prove_n(self, i, n):
         ptr = None if self.io else self.d_traces[i].data_ptr()
-        for _ in range(n):
-            self.ctxs[i].check(self.starks[i].prove_raw(self.tts[i], trace_device_ptr=ptr, read_fri_proof=self.io))
+        for _ in range(n):   # io: the read-back of proof k (copy stream) overlaps the first stages of proof k + 1; the last one is waited for below
+            self.ctxs[i].check(self.starks[i].prove_raw(self.tts[i], trace_device_ptr=ptr, read_fri_proof="async" if self.io else False))
+        if self.io:
+            self.ctxs[i].check(self.starks[i].wait_proof())
         self.last[i] = self.starks[i].last_proof(read_fri_proof=False)
 
     def run(self, n):  # n steps = n proofs on each lane (ctypes releases the GIL inside the library)
@@ -376,7 +378,7 @@ def main():
             leg("goldilocks_2p24_rows", lambda: dict(proofs_leg(0, 24, 4, 1), workload="BASELINE configs[3] per GPU: Fibonacci AIR, Goldilocks, 2^24 rows, blowup 8 (L = 2^27, ~25 GiB resident per proof)"))
             leg("babybear_fp4_2p20_rows", lambda: dict(proofs_leg(1, 20, 10, 2), workload="BASELINE configs[2]: Fibonacci AIR, BabyBear + quartic extension, 2^20 rows, blowup 8 (u32 storage)"))
             leg("value_with_io", lambda: dict(proofs_leg(0, 20, 10, 2, io=True), workload="configs[1] with the boundary's I/O inside the timed region: every proof uploads its 24 MiB trace from page-locked "
-                                              "host memory and reads its ~64 MiB FRI proof back into page-locked host memory (PCIe Gen5 x16), overlapped across the in-flight lanes"))
+                                              "host memory and reads its ~64 MiB FRI proof back into page-locked host memory (PCIe Gen5 x16; ms_fri_proof_read_async: the read-back of a lane's proof k runs on its copy stream while proof k + 1 starts, every read-back finished inside the timed region), overlapped across the in-flight lanes"))
 
             def ntt_only():
                 res = {}

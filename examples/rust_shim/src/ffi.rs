@@ -62,6 +62,8 @@ extern "C" {
     pub fn ms_fri_query(ctx: *mut ms_ctx, betas: *const u64, nq: c_int) -> c_int;
     pub fn ms_fri_proof_size(ctx: *const ms_ctx) -> usize;
     pub fn ms_fri_proof_read(ctx: *mut ms_ctx, out: *mut u8) -> c_int;
+    pub fn ms_fri_proof_read_async(ctx: *mut ms_ctx, out: *mut u8) -> c_int;
+    pub fn ms_fri_proof_wait(ctx: *mut ms_ctx) -> c_int;
     // ---- Tree trait (src/merkle.rs:8-30) on its own
     pub fn ms_merkle_commit(ctx: *mut ms_ctx, leafs: *const u64, leaf_num: usize, ext: c_int, lpn: usize, ic: usize,
                             nodes_out: *mut u8, nodes_cap: usize, nnodes: *mut usize, root: *mut u8) -> c_int;

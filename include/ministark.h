@@ -153,6 +153,11 @@ int ms_fri_round_codeword_read(ms_ctx* ctx, int round, uint64_t* out /* D*E */);
 int ms_fri_query(ms_ctx* ctx, const uint64_t* betas, int nq);
 size_t ms_fri_proof_size(const ms_ctx* ctx);
 int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out);
+/* The same read-back without blocking: the copy runs on the context's own copy stream behind the query phase and `out` (page-locked:
+ * ms_pinned_alloc) is complete once ms_fri_proof_wait returns; the next proof's stages may be issued meanwhile - the next
+ * ms_fri_query orders itself behind the copy on the device.  One read-back in flight per context. */
+int ms_fri_proof_read_async(ms_ctx* ctx, uint8_t* out);
+int ms_fri_proof_wait(ms_ctx* ctx);
 /* MSFP layout — for each window (previous, round) in order, for each beta in order:
  *     6*E u64   x1 y1 x2 y2 x3 y3                      (FriProof.points,    fri.rs:148-154)
  *     u64 qlen, qlen*E u64 quotient coefficients       (FriProof.quotients, fri.rs:159-167)

@@ -39,6 +39,10 @@ size_t msh_proof_arthur(const msh_stark* h, uint8_t* out, size_t cap);
 int msh_proof_commits(const msh_stark* h, uint8_t* trace_commit, uint8_t* lde_commit);
 size_t msh_proof_evals(const msh_stark* h, uint64_t* out, size_t cap_elems);
 size_t msh_proof_fri_roots(const msh_stark* h, uint8_t* out, size_t cap);
+/* read_fri_proof of msh_stark_prove: 0 = the FRI proof stays in HBM, 1 = read back before returning, 2 = read back asynchronously
+ * (ms_fri_proof_read_async: the bytes travel into the mirror's page-locked buffer while the caller goes on, e.g. into the next
+ * msh_stark_prove); msh_proof_wait - and every accessor below that touches the blob - waits for them. */
+int msh_proof_wait(const msh_stark* h);
 size_t msh_proof_fri_blob(const msh_stark* h, uint8_t* out, size_t cap);
 size_t msh_proof_challenges(const msh_stark* h, uint64_t* out, size_t cap_elems);
 size_t msh_proof_num_polys(const msh_stark* h);

@@ -82,6 +82,8 @@ struct CtxBase {
   virtual int fri_query(const u64* betas, int nq) = 0;
   virtual size_t fri_proof_size() const = 0;
   virtual int fri_proof_read(u8* out) = 0;
+  virtual int fri_proof_read_async(u8* out) = 0;
+  virtual int fri_proof_wait() = 0;
   virtual int merkle_commit(const u64* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, u8* nodes_out, size_t cap, size_t* nn, u8* root) = 0;
   virtual int merkle_prove(const u64* leafs, size_t leaf_num, int ext, size_t lpn, const u64* leaf, u8* out, size_t cap, size_t* len) = 0;
   virtual int ntt(u64* data, size_t n, size_t batch, int inverse) = 0;
@@ -774,6 +776,10 @@ template <class F> struct Ctx : CtxBase {
   ~Ctx() {
     for (auto& kv : plans) { kv.second->tw_lo.release(); kv.second->tw_hi.release(); kv.second->vtw.release(); kv.second->w0.release(); for (auto& b : kv.second->w_r) b.release(); delete kv.second; }
     drop_rccl();
+    if (copy_pending) msrt::event_sync(ev_copy);
+    if (ev_blob) msrt::event_destroy(ev_blob);
+    if (ev_copy) msrt::event_destroy(ev_copy);
+    if (copy_stream) msrt::stream_destroy(copy_stream);
     for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
     DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero};
     for (DevBuf* b : bufs) b->release();
@@ -1344,6 +1350,9 @@ template <class F> struct Ctx : CtxBase {
     size_t sh_elems = 0;
     for (size_t i = 0; i <= W; i++) sh_elems += (size_t)nq * (sh_scratch_elems((rounds[i]->ncoef + 1) / 2) + sh_scratch_elems(rounds[i]->ncoef / 2));
     const size_t n_h0 = (W + 1) * nq * 2 * E, n_tg = (W ? W : 1) * 2 * nq * E;
+    if (copy_pending) {   // an asynchronous read-back of the previous proof: finish it before the blob moves, order it before the blob is rewritten
+      if (pos + 8 > d_blob.cap) RQ(fri_proof_wait()); else CK(msrt::stream_wait_event(stream, ev_copy));
+    }
     if (d_blob.ensure(pos + 8) || d_sh.ensure(sh_elems * sizeof(T)) || d_targets.ensure((n_h0 + n_tg) * sizeof(T)) || d_idx.ensure((W ? W : 1) * nq * 2 * 8))
       return fail(MS_ERR_NOMEM, "query buffers");
     u8* blob = d_blob.as<u8>();
@@ -1492,8 +1501,26 @@ template <class F> struct Ctx : CtxBase {
   size_t fri_proof_size() const override { return blob_size; }
   int fri_proof_read(u8* out) override {
     if (!blob_size || !out) return fail(MS_ERR_STATE, "no FRI proof");
+    RQ(fri_proof_wait());
     CK(msrt::d2h(out, d_blob.p, blob_size, stream));
     CK(msrt::sync(stream));
+    return MS_OK;
+  }
+  // The same copy on the context's COPY stream, ordered behind the query phase by an event: the call returns at once and the next proof's
+  // stages run while the ~64 MiB travel; the next ms_fri_query waits (on the device, not on the host) for the copy before it rewrites the blob.
+  msrt::Stream* copy_stream = nullptr; msrt::Event* ev_blob = nullptr; msrt::Event* ev_copy = nullptr; bool copy_pending = false;
+  int fri_proof_read_async(u8* out) override {
+    if (!blob_size || !out) return fail(MS_ERR_STATE, "no FRI proof");
+    if (!copy_stream) { CK(msrt::stream_create(&copy_stream)); CK(msrt::event_create(&ev_blob)); CK(msrt::event_create(&ev_copy)); }
+    CK(msrt::event_record(ev_blob, stream));
+    CK(msrt::stream_wait_event(copy_stream, ev_blob));
+    CK(msrt::d2h(out, d_blob.p, blob_size, copy_stream));
+    CK(msrt::event_record(ev_copy, copy_stream));
+    copy_pending = true;
+    return MS_OK;
+  }
+  int fri_proof_wait() override {
+    if (copy_pending) { CK(msrt::event_sync(ev_copy)); copy_pending = false; }
     return MS_OK;
   }
 
@@ -1702,6 +1729,8 @@ int ms_fri_round_codeword_read(ms_ctx* ctx, int r, uint64_t* out) { CTX_OR_FAIL;
 int ms_fri_query(ms_ctx* ctx, const uint64_t* betas, int nq) { CTX_OR_FAIL; return B(ctx)->fri_query(betas, nq); }
 size_t ms_fri_proof_size(const ms_ctx* ctx) { return ctx ? B(ctx)->fri_proof_size() : 0; }
 int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out) { CTX_OR_FAIL; return B(ctx)->fri_proof_read(out); }
+int ms_fri_proof_read_async(ms_ctx* ctx, uint8_t* out) { CTX_OR_FAIL; return B(ctx)->fri_proof_read_async(out); }
+int ms_fri_proof_wait(ms_ctx* ctx) { CTX_OR_FAIL; return B(ctx)->fri_proof_wait(); }
 int ms_merkle_commit(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, uint8_t* nodes_out, size_t cap, size_t* nn, uint8_t root[32]) {
   CTX_OR_FAIL; return B(ctx)->merkle_commit(leafs, leaf_num, ext, lpn, ic, nodes_out, cap, nn, root);
 }

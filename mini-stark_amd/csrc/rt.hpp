@@ -44,6 +44,8 @@ inline int event_create(Event** e) { *e = new Event(); return 0; }
 inline int event_destroy(Event* e) { delete e; return 0; }
 inline int event_record(Event*, Stream*) { return 0; }
 inline int event_elapsed_ms(float* ms, Event*, Event*) { *ms = 0.f; return 0; }
+inline int stream_wait_event(Stream*, Event*) { return 0; }
+inline int event_sync(Event*) { return 0; }
 template <class K>
 inline int launch(Stream*, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
   std::vector<unsigned char> lds(lds_bytes + 16);
@@ -162,6 +164,8 @@ inline int event_create(Event** e) { return (int)hipEventCreate(e); }
 inline int event_destroy(Event* e) { return (int)hipEventDestroy(e); }
 inline int event_record(Event* e, Stream* s) { return (int)hipEventRecord(e, s); }
 inline int event_elapsed_ms(float* ms, Event* a, Event* b) { return (int)hipEventElapsedTime(ms, a, b); }
+inline int stream_wait_event(Stream* s, Event* e) { return (int)hipStreamWaitEvent(s, e, 0); }
+inline int event_sync(Event* e) { return (int)hipEventSynchronize(e); }
 
 // ---- RCCL, bound at run time (dlopen: the library neither links against nor requires librccl unless ms_set_shard_rccl is used).
 // Only the handful of entry points the sharded proof needs; types restated from <rccl/rccl.h> (ncclUniqueId = 128 opaque bytes,

@@ -75,7 +75,12 @@ class HostStark:
         host_ptr = None if trace_device_ptr is not None else trace.data.ctypes.data_as(C.POINTER(C.c_uint64))
         return self.H.msh_stark_prove(self.h, host_ptr, C.c_void_p(trace_device_ptr), C.c_size_t(trace.length), C.c_size_t(trace.width), C.c_int(len(k)),
                                       k.ctypes.data_as(C.POINTER(C.c_int)), sc.ctypes.data_as(C.POINTER(C.c_uint64)), ix.ctypes.data_as(C.POINTER(C.c_int)),
-                                      C.c_int(1 if read_fri_proof else 0))
+                                      C.c_int(2 if read_fri_proof == "async" else (1 if read_fri_proof else 0)))
+
+    def wait_proof(self):
+        """Completes an asynchronous read-back (read_fri_proof="async": the FRI proof travels into the mirror's page-locked buffer while
+        the next proof is already being computed)."""
+        return self.H.msh_proof_wait(self.h)
 
     def _bytes(self, fn):
         n = fn(self.h, None, C.c_size_t(0))

@@ -150,7 +150,10 @@ struct StarkConfig {  // src/starks.rs:238-333
 struct Stark {
   StarkConfig cfg; StarkProof proof;
   // src/starks.rs:59-169
-  int prove(const TraceTable& trace, bool read_fri_proof) {
+  // read_fri_proof: 0 the FRI proof stays in HBM; 1 read back before returning; 2 read back ASYNCHRONOUSLY (ms_fri_proof_read_async: the bytes
+  // land in the page-locked buffer while the caller goes on - e.g. into the next prove; wait_proof() / any accessor of the blob completes it)
+  int wait_proof() const { return cfg.ctx ? ms_fri_proof_wait(cfg.ctx) : 0; }
+  int prove(const TraceTable& trace, int read_fri_proof) {
     const StarkConfig& c = cfg; ms_ctx* ctx = c.ctx; const int e = c.e; const u64 p = c.p;
     StarkProof& pr = proof;
     pr.arthur.clear(); pr.evals.clear(); pr.fri_roots.clear(); pr.challenges.clear(); pr.c = 0; pr.fri_blob.n = 0;   // the page-locked proof buffer is kept across proofs
@@ -199,8 +202,9 @@ struct Stark {
     if ((rc = ms_fri_query(ctx, betas.data(), (int)betas.size()))) return rc;
     pr.challenges.insert(pr.challenges.end(), betas.begin(), betas.end());
     if (read_fri_proof) {
+      if ((rc = ms_fri_proof_wait(ctx))) return rc;          // an earlier asynchronous read-back into this buffer (long finished by now)
       pr.fri_blob.resize_uninit(ms_fri_proof_size(ctx));
-      if (!pr.fri_blob.empty() && (rc = ms_fri_proof_read(ctx, pr.fri_blob.data()))) return rc;
+      if (!pr.fri_blob.empty() && (rc = (read_fri_proof == 2 ? ms_fri_proof_read_async(ctx, pr.fri_blob.data()) : ms_fri_proof_read(ctx, pr.fri_blob.data())))) return rc;
     }
     pr.arthur = t.prover_bytes;                                                 // starks.rs:160
     return MS_OK;
@@ -390,13 +394,14 @@ int msh_stark_prove(msh_stark* h, const u64* trace_host, const void* trace_dev, 
     Lincomb l; l.scalars.assign(tr_scalars + off, tr_scalars + off + tr_k[i]); l.idx.assign(tr_idx + off, tr_idx + off + tr_k[i]);
     off += tr_k[i]; t.transitions.push_back(l);
   }
-  return h->s.prove(t, read_fri_proof != 0);
+  return h->s.prove(t, read_fri_proof);
 }
 size_t msh_proof_arthur(const msh_stark* h, u8* out, size_t cap) { return copy_out(h->s.proof.arthur.data(), h->s.proof.arthur.size(), out, cap); }
 int msh_proof_commits(const msh_stark* h, u8* trace_commit, u8* lde_commit) { memcpy(trace_commit, h->s.proof.trace_commit, 32); memcpy(lde_commit, h->s.proof.constrain_trace_commit, 32); return 0; }
 size_t msh_proof_evals(const msh_stark* h, u64* out, size_t cap_elems) { return copy_out(h->s.proof.evals.data(), h->s.proof.evals.size() * 8, out, cap_elems * 8) / 8; }
 size_t msh_proof_fri_roots(const msh_stark* h, u8* out, size_t cap) { return copy_out(h->s.proof.fri_roots.data(), h->s.proof.fri_roots.size(), out, cap); }
-size_t msh_proof_fri_blob(const msh_stark* h, u8* out, size_t cap) { return copy_out(h->s.proof.fri_blob.data(), h->s.proof.fri_blob.size(), out, cap); }
+int msh_proof_wait(const msh_stark* h) { return h->s.wait_proof(); }
+size_t msh_proof_fri_blob(const msh_stark* h, u8* out, size_t cap) { h->s.wait_proof(); return copy_out(h->s.proof.fri_blob.data(), h->s.proof.fri_blob.size(), out, cap); }
 size_t msh_proof_challenges(const msh_stark* h, u64* out, size_t cap_elems) { return copy_out(h->s.proof.challenges.data(), h->s.proof.challenges.size() * 8, out, cap_elems * 8) / 8; }
 size_t msh_proof_num_polys(const msh_stark* h) { return h->s.proof.c; }
 // Stark::verify (src/starks.rs:171-235) of a proof given by its parts; `constrains` = the c constraint polynomials in coefficient
@@ -423,6 +428,7 @@ static const size_t MSSP_HEAD = 4 + 5 * 4 + 2 * 8;
 // bytes needed for the last proof of `h` (0: no proof, or its FRI proof was left in HBM); writes them when cap suffices
 size_t msh_proof_serialize(const msh_stark* h, u8* out, size_t cap) {
   const StarkProof& pr = h->s.proof; const StarkConfig& c = h->s.cfg;
+  h->s.wait_proof();   // an asynchronous read-back of the FRI proof
   if (pr.arthur.empty() || pr.fri_blob.empty()) return 0;
   const u32 e = (u32)c.e, cc = (u32)pr.c, q = (u32)c.constrain_queries, rounds = (u32)(pr.fri_roots.size() / 32);
   const size_t need = MSSP_HEAD + 64 + pr.evals.size() * 8 + pr.fri_roots.size() + pr.arthur.size() + pr.fri_blob.size();

@@ -397,3 +397,27 @@ def test_babybear_on_the_round2_tiles(mk, monkeypatch):
 @pytest.mark.parametrize("field", [0, 1])
 def test_lincomb_shared_sweep(mk, field):
     pc.case_lincomb_shared_sweep(lambda f: mk(f, fresh=True), field, log_n=12)
+
+
+@pytest.mark.gpu
+def test_async_proof_readback_on_gpu(mk):
+    """ms_fri_proof_read_async: the 2^16-row proofs' FRI bytes arrive through the copy stream while the next proof is computed, identical
+    to the blocking read-back; the next query phase orders itself behind the copy on the device."""
+    from mini_stark_amd.host import HostStark
+    from mini_stark_amd.stark import fibonacci_air
+    ctx = mk(0, fresh=True)
+    steps, blowup = (1 << 16) - 1, 8
+    tts = [fibonacci_air(ctx, steps, secret_b=b) for b in (2, 7, 11)]
+    hs = HostStark(ctx, 20, blowup, steps, tts[0].constrain_number())
+    want = [hs.prove(tt).fri_proof.blob for tt in tts]
+    assert len(set(want)) == 3
+    for rep in range(2):
+        got = []
+        for tt in tts:
+            ctx.check(hs.prove_raw(tt, read_fri_proof="async"))
+            if rep == 0:
+                got.append(hs.last_proof().fri_proof.blob)   # accessor waits
+        if rep == 0:
+            assert got == want
+    assert hs.wait_proof() == 0
+    assert hs.last_proof().fri_proof.blob == want[-1]

@@ -233,3 +233,23 @@ def test_mssp_roundtrip_across_processes_emulation(emu, tmp_path):
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "verify_worker.py"), str(f), "0", "63", "8", emu],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "VERIFY accepted tampered-rejected" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_async_proof_readback_matches_blocking(emu, field):
+    """read_fri_proof="async" (ms_fri_proof_read_async on the context's copy stream, the next prove issued before the bytes are awaited)
+    delivers the same FRI proof bytes as the blocking read-back, proof after proof on one context."""
+    ctx = ms.Context(field, lib_path=emu)
+    steps, blowup = 63, 8
+    tts = [fibonacci_air(ctx, steps, secret_b=b) for b in (2, 5, 9)]
+    hs = HostStark(ctx, 20, blowup, steps, tts[0].constrain_number())
+    want = [hs.prove(tt).fri_proof.blob for tt in tts]
+    assert len(set(want)) == 3
+    for k, tt in enumerate(tts):   # asynchronous: the accessor waits
+        ctx.check(hs.prove_raw(tt, read_fri_proof="async"))
+        assert hs.last_proof().fri_proof.blob == want[k]
+    for tt in tts:                 # back to back without looking at the bytes in between, explicit wait at the end
+        ctx.check(hs.prove_raw(tt, read_fri_proof="async"))
+    assert hs.wait_proof() == 0
+    assert hs.last_proof().fri_proof.blob == want[-1]
+    ctx.close()
