@@ -14,4 +14,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write --
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-extras > $O/pmc_sq.log 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate > $O/valu_rate.txt 2>&1 || true   # built from source every time (the binary is not tracked)
 hipcc --offload-arch=gfx950 -O2 tools/latency_probe.hip -o /tmp/latency_probe 2>/dev/null && timeout -k 5 120 /tmp/latency_probe > $O/latency_probe.txt 2>&1 || true
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mini-stark_amd/csrc tools/sha_lab.hip -o /tmp/sha_lab 2>/dev/null && timeout -k 5 100 /tmp/sha_lab > $O/sha_lab.log 2>&1 || true          # SHA-256 on registers only: the hash kernels' ceiling
+hipcc --offload-arch=gfx950 -O3 tools/stride_probe.hip -o /tmp/stride_probe 2>/dev/null && timeout -k 5 120 /tmp/stride_probe > $O/stride_probe.log 2>&1 || true            # access pattern of the NTT later pass, no arithmetic
+timeout -k 10 300 python3 tools/io_probe.py 2>/dev/null | grep '^{' > $O/io_probe.log || true                                                                              # upload / read-back split of the I/O-inclusive rate
 ls $O
