@@ -533,6 +533,19 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     if constexpr (J + 1 < NJ) sub_items<SR, J + 1, MG>(tid, tile, w);
   }
 
+  // first sub-round whose 2^B0 inputs are already in the lane's registers (FUSE_HEAD): x[t] = element (row lo + t * 2^SLO(0), column c)
+  template <bool MG> static MS_DEV void sub0_regs(T (&x)[1 << DG::bits(0)], int tid, T* tile, const T* w) {
+    constexpr int B = DG::bits(0), SLO = DG::slo(0);   // FUSE_HEAD guarantees SLO >= BL + 2: the row swizzle does not touch this digit
+    const int c = tid & (C - 1), lo = tid >> LC;                     // one item per lane: g = lo (the top digit is the only one above)
+    T* base = tile + ((lo ^ ((lo >> BL) & 3)) * C + c);
+    dif_regs<A, INV, B>(x, w, K);
+#pragma unroll
+    for (int e = 0; e < (1 << B); e++) {
+      T v = x[bitrev(e, B)];
+      if (e != 0) v = A::mul_tw(v, MG ? w[(e << SLO) + lo] : w[(e * lo) << (K - SLO - B)]);
+      base[(e << SLO) * C] = v;
+    }
+  }
   // ---- cooperative, persistent form: a workgroup walks tiles g = bx, bx + nbx, ... of the nbatch * tiles of the launch, and the
   // global loads of its NEXT tile are issued into registers right after the first sub-round, so that they are in flight during the
   // remaining sub-rounds and the store of the current one.  Measured before this change (profiles/r02_*): with a load burst at the
@@ -578,6 +591,16 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #endif
   static constexpr int TAIL_ITEMS = (R >> BL) * LPR, NJT = (TAIL_ITEMS + TH - 1) / TH;
   static constexpr bool FUSE_TAIL = MS_NTT_FUSE_TAIL != 0 && MODE != 0 && NSUB == 3 && TAIL_ITEMS % TH == 0 && !PREFETCH;
+  // Fused head (behind the virtual pass): the lane that expands coefficient row (tid >> LC) + j * 2^SLO(0) into column tid & (C - 1) is the lane
+  // whose first sub-round takes exactly these 2^B0 elements - they stay in registers, the tile is first written by the first sub-round
+  // (one LDS round trip less per element; the barrier stays: the boundary table and the reuse of the staging region need it).
+  // OFF: the 2^B0 elements held across that barrier and the table builds push the 2^10-row instance to 128 VGPRs + 10 spilled (44 bytes
+  // of scratch) and the LDE 6 x 2^20 -> 2^23 from 0.583 to 0.593 ms (two interleaved pairs of runs); bit-exact on the emulator.
+#ifndef MS_NTT_FUSE_HEAD
+#define MS_NTT_FUSE_HEAD 0
+#endif
+  static constexpr bool FUSE_HEAD = MS_NTT_FUSE_HEAD != 0 && MODE == 2 && !PREFETCH && MS_NTT_STAGE_SRC != 0 && (TH >> LC) == (1 << DG::slo(0)) &&
+                                    ((R >> DG::bits(0)) * C) == TH && (R * C / TH) == (1 << DG::bits(0)) && DG::slo(0) >= BL + 2;
   static constexpr int DMA_ROWS = 1024 / (C * (int)sizeof(T)), DMA_INST = R / DMA_ROWS / (TH / 64);   // rows per wave instruction (1 KiB), instructions per wave and tile
   static constexpr bool DMA = MS_NTT_DMA != 0 && FUSE_TAIL && MODE == 1 && (C * (int)sizeof(T)) == 64 && R % (DMA_ROWS * (TH / 64)) == 0;
   // LDS slot s of the swizzled tile holds row s ^ ((s >> BL) & 3) (prow is an involution): the swizzle goes on the SOURCE address, the wave's
@@ -667,6 +690,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     constexpr bool STAGE = MODE == 2 && !PREFETCH && MS_NTT_STAGE_SRC;
     constexpr int NS = STAGE ? (R + TH - 1) / TH : 1;
     T sv[NS];
+    [[maybe_unused]] T xh[FUSE_HEAD ? (1 << DG::bits(0)) : 1];   // FUSE_HEAD: the first sub-round's inputs
     auto stage_issue = [&](size_t tile_, size_t by_) {
       const size_t nprime = ((size_t)1 << p.log_n) >> (LC + K);
       const T* src = p.src + by_ * p.src_bstride;
@@ -734,6 +758,16 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
               w[idx] = v;
             }
           }
+          if constexpr (FUSE_HEAD) {
+            const int i1 = tid & (C - 1), row0 = tid >> LC;
+#pragma unroll
+            for (int j = 0; j < (1 << DG::bits(0)); j++) {
+              const int row = row0 + (j << DG::slo(0));
+              T v = twr[row];
+              if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
+              xh[j] = v;
+            }
+          } else
 #pragma unroll MS_NTT_VLOAD_UNROLL
           for (int idx = tid; idx < R * C; idx += TH) {
             const int row = idx >> LC, i1 = idx & (C - 1);
@@ -783,7 +817,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         stage_issue(ntl, nby);
       }
 #ifndef MS_ABL_NOCOMPUTE   // ablation builds (tools/ntt_ablate.sh): memory-only / compute-only timings of the same kernel
-      sub_items<0, 0, MERGE>(tid, tile, w);
+      if constexpr (FUSE_HEAD) sub0_regs<MERGE>(xh, tid, tile, w); else sub_items<0, 0, MERGE>(tid, tile, w);
 #endif
       msrt::wg_barrier();
       if (PREFETCH && it + stride < lim) {   // next tile's loads: in flight during the remaining sub-rounds and the store
