@@ -46,12 +46,99 @@ def default_inflight(log_rows):
     return 8 if log_rows <= 20 else (4 if log_rows == 21 else (3 if log_rows == 22 else 2))
 
 
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libministark_emu.so")
+
+
+def lib_path_for(args):
+    """None = the product library (HIP, gfx950).  --emu: the CPU emulation build of the same kernel source (tests/emu) - a REHEARSAL of the
+    launch / collective plumbing on a box without enough GPUs; its timings mean nothing and the JSON line says so."""
+    return EMU_LIB if getattr(args, "emu", False) else None
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_wave(argv, world, timeout, extra_env=None):
+    """N fresh child processes of this script, one rank each (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set): what
+    `python -m torch.distributed.run --nproc-per-node N` would start.  The parent never touches the GPU (no torch import, no HIP call).
+    Returns (rc, rank 0's stdout lines, stderr tail of the first failing rank)."""
+    import subprocess
+    import tempfile
+    env0 = dict(os.environ)
+    env0.update({"WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "MS_BENCH_LAUNCHED": "1"})
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env0.update(extra_env or {})
+    procs, outs = [], []
+    for r in range(world):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        fo = tempfile.TemporaryFile(mode="w+")
+        outs.append(fo)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=fo, stderr=None))
+    deadline = time.time() + timeout
+    rc, failed = 0, None
+    pending = set(range(world))
+    while pending and rc == 0:
+        for r in sorted(pending):
+            c = procs[r].poll()
+            if c is not None:
+                pending.discard(r)
+                if c != 0:
+                    rc, failed = c, r
+        if time.time() > deadline:
+            rc, failed = 124, -1
+        if pending and rc == 0:
+            time.sleep(0.05)
+    if rc != 0:   # one rank failed (or the wave timed out): end the others - exactly the PIDs started here
+        for r in pending:
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=20)
+            except Exception:
+                procs[r].kill()
+    outs[0].seek(0)
+    lines = outs[0].read().splitlines()
+    for fo in outs:
+        fo.close()
+    return rc, lines, failed
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without torchrun: start the N ranks here.  Wave 1 = the replicas leg (headline), wave 2 = the sharded
+    2^24-row proof (fresh processes again, so that neither a hang nor a crash of it can take the headline down); the parent merges rank 0's
+    two JSON lines into ONE line on stdout and exits non-zero if the headline wave failed."""
+    world = args.gpus
+    rc, lines, failed = _run_wave(argv, world, timeout=args.launch_timeout)
+    js = [l for l in lines if l.startswith("{")]
+    if rc != 0 or not js:
+        print(f"[bench] rank {failed} of the {world}-rank run failed with code {rc}" if rc else "[bench] rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        sys.exit(rc or 1)
+    out = json.loads(js[-1])
+    out["launcher"] = "bench.py (self-launched ranks; no torchrun)"
+    if args.mode == "replicas" and not args.no_shard_leg:
+        sargv = ["--gpus", str(world), "--mode", "shard", "--log-rows", str(args.shard_log_rows), "--steps", str(args.shard_steps), "--warmup", "1", "--backend", args.backend,
+                 "--field", str(args.field), "--blowup", str(args.blowup), "--no-cpu-baseline", "--no-extras"] + (["--emu"] if args.emu else [])
+        rc2, lines2, failed2 = _run_wave(sargv, world, timeout=args.shard_timeout)
+        js2 = [l for l in lines2 if l.startswith("{")]
+        if rc2 == 0 and js2:
+            out["sharded"] = json.loads(js2[-1])["exchange"]
+        elif rc2 == 124:
+            out["sharded"] = {"error": f"the sharded leg did not finish within {args.shard_timeout:.0f} s; headline unaffected"}
+        else:
+            out["sharded"] = {"error": f"sharded leg: rank {failed2} exited with code {rc2}; headline unaffected"}
+    print(json.dumps(out), flush=True)
+
+
 class Lanes:
     """`inflight` independent provers on one GPU: one ms_ctx (own HIP stream, own HBM buffers), one host thread and one C++
     host-mirror Stark each.  io=False: traces resident in HBM, FRI proofs left in HBM.  io=True: every proof uploads its trace
     from page-locked host memory and reads the FRI proof back into page-locked host memory."""
 
-    def __init__(self, field, log_rows, blowup, inflight, device_index, dev, seed0=2, io=False):
+    def __init__(self, field, log_rows, blowup, inflight, device_index, dev, seed0=2, io=False, lib=None):
         import numpy as np
         import torch
         import mini_stark_amd as ms
@@ -59,7 +146,7 @@ class Lanes:
         from mini_stark_amd.host import HostStark
         self.ms, self.io, self.n = ms, io, inflight
         steps = (1 << log_rows) - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
-        self.ctxs = [ms.Context(field, device=device_index) for _ in range(inflight)]
+        self.ctxs = [ms.Context(field, device=device_index, lib_path=lib) for _ in range(inflight)]
         self.tts = [fibonacci_air(c, steps, secret_b=seed0 + i) for i, c in enumerate(self.ctxs)]
         self.cfg = StarkConfig(self.ctxs[0], 20, blowup, steps, self.tts[0].constrain_number())
         self.starks = [HostStark(c, 20, blowup, steps, self.tts[0].constrain_number()) for c in self.ctxs]
@@ -70,7 +157,8 @@ class Lanes:
             self.d_traces = [None] * inflight
         else:
             self.d_traces = [torch.from_numpy(t.data.view(np.int64)).to(dev) for t in self.tts]  # resident in HBM before the timed region
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         self.last = [None] * inflight
 
     def _prove_n(self, i, n):
@@ -116,20 +204,22 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
     from mini_stark_amd.host import HostStark
     from mini_stark_amd.dist import RcclShard, ShardExchange
     N = 1 << log_rows
-    ctx = ms.Context(args.field, device=local_rank)
+    lib = lib_path_for(args)
+    ctx = ms.Context(args.field, device=local_rank, lib_path=lib)
     cap = 32 * N * args.blowup // grp.world + (4 << 20)   # leaf digests of the largest commitment / world + the query phase's Merkle paths
+    dev = torch.device("cpu") if args.emu else torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     if args.backend == "nccl":
         xchg = RcclShard(grp, ctx, cap)
         how = "RCCL inside the library (ms_set_shard_rccl): ncclSend/ncclRecv all-to-all of leaf digests + ncclAllGather of subtree roots per large commitment, 2 ncclAllReduce in the query phase, all on the prover's stream"
     else:
-        dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
-        xchg = ShardExchange(grp, ctx, cap, staged=True, buffer_device=dev)
+        xchg = ShardExchange(grp, ctx, cap, staged=not args.emu, buffer_device=dev)
         how = "gloo rehearsal through the exchange callback (payloads staged through host memory)"
     tt = fibonacci_air(ctx, N - 1)   # every rank holds the same trace
     cfg = StarkConfig(ctx, 20, args.blowup, N - 1, tt.constrain_number())
     hs = HostStark(ctx, 20, args.blowup, N - 1, tt.constrain_number())
-    d_trace = torch.from_numpy(tt.data.view("int64")).to(torch.device("cuda", local_rank % max(1, torch.cuda.device_count())))
-    torch.cuda.synchronize()
+    d_trace = torch.from_numpy(tt.data.view("int64")).to(dev)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
 
     def prove(n):
         for _ in range(n):
@@ -140,11 +230,28 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
     prove(steps)
     grp.barrier()
     el = grp.max_over_ranks(time.perf_counter() - t0)
-    roots = grp.all_gather_bytes(hs.last_proof(read_fri_proof=False).fri_roots[-1])
+    mine = hs.last_proof(read_fri_proof=False)
+    roots = grp.all_gather_bytes(mine.fri_roots[-1])
     calls = xchg.calls
+    # the same trace proved UNSHARDED by rank 0 on a second context: pins the exchange path (a symmetric error - wrong chunk order in the
+    # all-to-all, a mistake in the in-place all-reduce - gives every rank the same wrong root and would pass `all_ranks_same_final_root`)
+    matches = None
+    if grp.rank == 0 and not args.no_shard_check:
+        c1 = ms.Context(args.field, device=local_rank, lib_path=lib)
+        h1 = HostStark(c1, 20, args.blowup, N - 1, tt.constrain_number())
+        c1.check(h1.prove_raw(tt, trace_device_ptr=d_trace.data_ptr(), read_fri_proof=False))
+        ref = h1.last_proof(read_fri_proof=False)
+        matches = {"trace_root": ref.trace_commit == mine.trace_commit, "lde_root": ref.constrain_trace_commit == mine.constrain_trace_commit,
+                   "all_fri_roots": list(ref.fri_roots) == list(mine.fri_roots), "deep_values": bool((ref.constrain_queries == mine.constrain_queries).all() and (ref.validity_queries == mine.validity_queries).all()),
+                   "transcript": ref.arthur == mine.arthur}
+        matches["all"] = all(matches.values())
+        del h1
+        c1.close()
+    grp.barrier()
     res = {"workload": f"Fibonacci AIR, {'Goldilocks' if args.field == 0 else 'BabyBear+Fp4'}, 2^{log_rows} trace rows, blowup {args.blowup} (rounds={cfg.rounds}): ONE proof per step over {grp.world} ranks",
            "scaling": "strong", "value": steps / el, "unit": "proofs/s", "ms_per_proof": el / steps * 1e3, "steps": steps, "warmup": warmup,
            "ranks_in_communicator": grp.world, "parallelism": how, "all_ranks_same_final_root": len(set(roots)) == 1,
+           "matches_unsharded": matches,
            "collective_calls_per_rank": {n: calls[i] for i, n in enumerate(["all_to_all", "all_gather", "all_reduce_min", "all_reduce_sum"])},
            "bytes_sent_per_rank": xchg.bytes, "proofs": steps + warmup}
     xchg.close()
@@ -184,7 +291,20 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL, one GPU per rank (the measured configuration).  gloo: rehearsal of the N>1 paths on a box with fewer GPUs than ranks "
                          "(ranks share GPUs, exchange payloads are staged through host memory)")
+    ap.add_argument("--emu", action="store_true", help="REHEARSAL on the CPU: the kernel-emulation build of the same source (tests/emu) instead of the HIP library, host memory "
+                                                    "instead of HBM, backend gloo; exercises the launcher, the rank plumbing and the sharded leg's exchange without a GPU.  Timings are meaningless")
+    ap.add_argument("--no-shard-check", action="store_true", help="sharded leg: skip rank 0's unsharded proof of the same trace (matches_unsharded)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="time limit of the self-launched ranks (--gpus N > 1 without torchrun), seconds")
     args = ap.parse_args()
+    if args.emu:
+        args.backend = "gloo"
+    # --gpus N > 1 started as a plain `python bench.py` (no torchrun, WORLD_SIZE unset): this process becomes the launcher of N ranks
+    # and never touches the GPU itself.  Under torchrun (WORLD_SIZE set) the process IS one rank.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])
+        return
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: the launcher's world size wins", file=sys.stderr, flush=True)
 
     import numpy as np
     import torch
@@ -192,9 +312,13 @@ def main():
     from mini_stark_amd.dist import Group
     grp = Group(args.backend)
     world, rank, local_rank, dev = grp.world, grp.rank, grp.local_rank, grp.device
-    if args.backend == "gloo":
+    lib = lib_path_for(args)
+    if args.emu:
+        local_rank, dev = 0, torch.device("cpu")
+    elif args.backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())
         dev = torch.device("cuda", local_rank)
+    launched = os.environ.get("MS_BENCH_LAUNCHED") == "1"   # a rank of bench.py's own launcher: the parent runs the sharded leg as a second wave
     if args.inflight is None:
         args.inflight = default_inflight(args.log_rows)
     field_name = "Goldilocks" if args.field == 0 else "BabyBear+Fp4"
@@ -211,7 +335,7 @@ def main():
         return
 
     # ---- headline leg: independent proofs on every rank
-    lanes = Lanes(args.field, args.log_rows, args.blowup, max(1, args.inflight), local_rank, dev, seed0=2 + rank * max(1, args.inflight))
+    lanes = Lanes(args.field, args.log_rows, args.blowup, max(1, args.inflight), local_rank, dev, seed0=2 + rank * max(1, args.inflight), lib=lib)
     cfg, C_IN = lanes.cfg, lanes.n
     elapsed = lanes.timed(grp, args.steps, args.warmup)
     final_roots = grp.all_gather_bytes(lanes.last[0].fri_roots[-1])  # every rank finished a proof (outside the timed region)
@@ -228,11 +352,14 @@ def main():
     # ---- N > 1: the sharded proof of BASELINE configs[3] as a second leg.  It runs in a CHILD process per rank (this script in --mode shard,
     # its own rendezvous on MASTER_PORT + 1): the RCCL path inside the library has never run on more than one GPU, and neither a hang
     # (subprocess timeout) nor a crash of it may take the headline down.
-    if world > 1 and not args.no_shard_leg:
+    if args.emu:
+        out["emulation"] = "REHEARSAL: CPU emulation build of the kernel source, host memory, gloo - exercises launcher / rank plumbing / exchange only; timings are meaningless"
+    if world > 1 and not args.no_shard_leg and not launched:
         import subprocess
         lanes.close()
         lanes = None
-        torch.cuda.empty_cache()
+        if not args.emu:
+            torch.cuda.empty_cache()
         if rank == 0:   # stderr only (stdout carries exactly one JSON line)
             print(f"[bench] replicas leg done: {out['value']:.2f} proofs/s on {world} GPUs; starting the sharded leg in child processes", file=sys.stderr, flush=True)
         grp.barrier()
@@ -240,7 +367,7 @@ def main():
         env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # torchrun's workers use the agent's store on MASTER_PORT; the children host their own on the next port
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--mode", "shard", "--log-rows", str(args.shard_log_rows), "--steps", str(args.shard_steps),
-               "--warmup", "1", "--backend", args.backend, "--field", str(args.field), "--blowup", str(args.blowup), "--no-cpu-baseline", "--no-extras"]
+               "--warmup", "1", "--backend", args.backend, "--field", str(args.field), "--blowup", str(args.blowup), "--no-cpu-baseline", "--no-extras"] + (["--emu"] if args.emu else [])
         try:
             cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.shard_timeout)
             lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
@@ -256,7 +383,9 @@ def main():
             if rank == 0:
                 out["sharded"] = {"error": f"{type(e).__name__}: {e}"}
 
-    if rank == 0:
+    if rank == 0 and args.emu:
+        print(json.dumps(out), flush=True)
+    elif rank == 0:
         if lanes is None:
             lanes = Lanes(args.field, args.log_rows, args.blowup, 1, local_rank, dev)
         ctx = lanes.ctxs[0]

@@ -7,7 +7,7 @@ Two ways to use N GPUs:
  * one proof sharded over the ranks (`ShardExchange`, ms_set_shard): the library partitions the
    evaluation-domain work of every large commitment and calls back here for the digest all-to-all, the
    subtree-root all-gather and the two small all-reduces of the query phase (include/ministark.h).
-Covered on CPU by tests/test_dist_gloo.py and tests/test_shard_gloo.py (gloo, world_size 2 and 4)."""
+Covered on CPU by tests/test_dist_gloo.py and tests/test_shard_gloo.py (gloo, world_size 2, 4 and 8) and tests/test_bench_launcher.py (bench.py self-launched, world 2 and 8)."""
 import os
 
 import torch

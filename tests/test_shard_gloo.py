@@ -22,7 +22,7 @@ def run_world(world, field, log_n, blowup, min_leaves, port):
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("world,field,log_n,blowup", [(2, 0, 8, 8), (4, 0, 9, 8), (2, 1, 7, 8), (4, 1, 8, 4), (2, 0, 6, 2)])
+@pytest.mark.parametrize("world,field,log_n,blowup", [(2, 0, 8, 8), (4, 0, 9, 8), (2, 1, 7, 8), (4, 1, 8, 4), (2, 0, 6, 2), (8, 0, 10, 8), (8, 1, 9, 8)])
 def test_sharded_proof_matches_oracle(world, field, log_n, blowup):
     res = run_world(world, field, log_n, blowup, 16, 29800 + world * 10 + field * 3 + log_n)
     assert res["world"] == world
