@@ -60,6 +60,7 @@ extern "C" {
     pub fn ms_fri_round_poly_read(ctx: *mut ms_ctx, round: c_int, out: *mut u64) -> c_int;
     pub fn ms_fri_round_codeword_read(ctx: *mut ms_ctx, round: c_int, out: *mut u64) -> c_int;
     pub fn ms_fri_query(ctx: *mut ms_ctx, betas: *const u64, nq: c_int) -> c_int;
+    pub fn ms_fri_query_into(ctx: *mut ms_ctx, betas: *const u64, nq: c_int, out: *mut u8, cap: usize, len: *mut usize) -> c_int;
     pub fn ms_fri_proof_size(ctx: *const ms_ctx) -> usize;
     pub fn ms_fri_proof_read(ctx: *mut ms_ctx, out: *mut u8) -> c_int;
     pub fn ms_fri_proof_read_async(ctx: *mut ms_ctx, out: *mut u8) -> c_int;
@@ -73,6 +74,7 @@ extern "C" {
     pub fn ms_ntt(ctx: *mut ms_ctx, data: *mut u64, n: usize, batch: usize, inverse: c_int) -> c_int;
     pub fn ms_coset_lde(ctx: *mut ms_ctx, coeffs: *const u64, ncoef: usize, batch: usize, shift: u64, out: *mut u64, l: usize) -> c_int;
     pub fn ms_bench_lde(ctx: *mut ms_ctx, blowup: usize, shift: u64) -> c_int;
+    pub fn ms_arith_selftest(ctx: *mut ms_ctx, op: c_int, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
     pub fn ms_profile_begin(ctx: *mut ms_ctx) -> c_int;
     pub fn ms_profile_end(ctx: *mut ms_ctx, json_out: *mut c_char, cap: usize) -> c_int;
 }

@@ -158,6 +158,12 @@ int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out);
  * ms_fri_query orders itself behind the copy on the device.  One read-back in flight per context. */
 int ms_fri_proof_read_async(ms_ctx* ctx, uint8_t* out);
 int ms_fri_proof_wait(ms_ctx* ctx);
+/* ms_fri_query with the FriProof written WHERE IT IS READ: the query-phase kernels store the MSFP blob straight into `out` - page-locked
+ * host memory from ms_pinned_alloc (mapped into the device's address space) or device memory - of `cap` bytes; no read-back copy.  The
+ * blob is complete when the call returns.  *len receives the blob size; with cap smaller than that nothing is computed and MS_ERR_ARG is
+ * returned (out = NULL, cap = 0: size query, MS_OK).  One buffer per proof in flight on the caller's side: the library keeps no reference to
+ * `out` after the call.  ms_fri_proof_read* do not apply to such a proof (MS_ERR_STATE). */
+int ms_fri_query_into(ms_ctx* ctx, const uint64_t* betas, int nq, uint8_t* out, size_t cap, size_t* len);
 /* MSFP layout — for each window (previous, round) in order, for each beta in order:
  *     6*E u64   x1 y1 x2 y2 x3 y3                      (FriProof.points,    fri.rs:148-154)
  *     u64 qlen, qlen*E u64 quotient coefficients       (FriProof.quotients, fri.rs:159-167)
@@ -189,6 +195,12 @@ int ms_bench_lde(ms_ctx* ctx, size_t blowup, uint64_t shift);
 /* measurement aid: between begin/end every kernel launch is bracketed by HIP events on the
  * launching stream; end() writes a JSON object {kernel: {launches, ms, alg_bytes}} (build-defined,
  * no reference counterpart). */
+/* diagnostic: out[i] = a[i] (op) b[i] computed ON THE DEVICE with the arithmetic class the NTT tiles use (Goldilocks: the exec-masked
+ * inline-asm class GLM, whose gfx950 wait states are managed by hand and which no CPU build can execute; BabyBear: BB) - so that a
+ * test can compare every operation with big-integer arithmetic on directed edge values.  a, b canonical.  op: 0 add, 1 sub, 2 mul,
+ * 3 mul by the table form of b (mul_tw(a, to_tw(b))), 4 a * 2^32, 5 a * 2^64, 6 a * 2^(b mod 96) through the compile-time shift
+ * chains of the butterflies (Goldilocks only), 7 fold: a + (b mod 2^31) * 2^64 mod p (Goldilocks only).  No reference counterpart. */
+int ms_arith_selftest(ms_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int ms_profile_begin(ms_ctx* ctx);
 int ms_profile_end(ms_ctx* ctx, char* json_out, size_t cap);
 

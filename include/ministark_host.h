@@ -27,6 +27,9 @@ typedef struct {
   const uint8_t *trace_commit, *constrain_trace_commit, *fri_roots, *arthur, *fri_blob;
   const uint64_t *constrain_queries, *validity_queries;
 } msh_proof_view;
+/* one MerklePath / one (window, query) record of the MSFP blob (ministark.h): views INTO the parsed buffer */
+typedef struct { uint64_t leaf_index, nlevels; const uint64_t* leaf_neighbours; /* 2*E */ const uint8_t* levels; /* nlevels * 2 * 32 */ } msh_merkle_path_view;
+typedef struct { const uint64_t* points; /* 6*E: x1 y1 x2 y2 x3 y3 */ uint64_t qlen; const uint64_t* quotient; /* qlen*E */ msh_merkle_path_view path[2]; } msh_fri_query_view;
 
 /* StarkConfig::new + Stark::new (starks.rs:268-310, 40-57); NULL and *err = MS_ERR_SHAPE for < 20 security bits (starks.rs:317-320) */
 msh_stark* msh_stark_new(ms_ctx* ctx, int field, uint64_t security_bits, uint64_t blowup, uint64_t steps, uint64_t trace_columns, int* err);
@@ -40,12 +43,20 @@ int msh_proof_commits(const msh_stark* h, uint8_t* trace_commit, uint8_t* lde_co
 size_t msh_proof_evals(const msh_stark* h, uint64_t* out, size_t cap_elems);
 size_t msh_proof_fri_roots(const msh_stark* h, uint8_t* out, size_t cap);
 /* read_fri_proof of msh_stark_prove: 0 = the FRI proof stays in HBM, 1 = read back before returning, 2 = read back asynchronously
- * (ms_fri_proof_read_async: the bytes travel into the mirror's page-locked buffer while the caller goes on, e.g. into the next
- * msh_stark_prove); msh_proof_wait - and every accessor below that touches the blob - waits for them. */
+ * (ms_fri_proof_read_async: the bytes travel into the slot's page-locked buffer while the caller goes on, e.g. into the next
+ * msh_stark_prove); msh_proof_wait - and every accessor below that touches the blob - waits for them; 3 = the query-phase kernels write
+ * the blob straight into the slot's page-locked buffer (ms_fri_query_into), complete on return.
+ * The mirror holds TWO proof slots: msh_stark_prove k + 1 reuses the slot of proof k - 1, so proof k stays whole (msh_prev_proof_*) while
+ * k + 1 is computed - including a mode-2 blob that is still arriving. */
 int msh_proof_wait(const msh_stark* h);
 size_t msh_proof_fri_blob(const msh_stark* h, uint8_t* out, size_t cap);
 size_t msh_proof_challenges(const msh_stark* h, uint64_t* out, size_t cap_elems);
 size_t msh_proof_num_polys(const msh_stark* h);
+size_t msh_prev_proof_arthur(const msh_stark* h, uint8_t* out, size_t cap);
+size_t msh_prev_proof_fri_roots(const msh_stark* h, uint8_t* out, size_t cap);
+size_t msh_prev_proof_fri_blob(const msh_stark* h, uint8_t* out, size_t cap);
+/* FNV-1a (64-bit words) over the FRI blob of the last (which = 0) / previous (which = 1) proof, read in place from its page-locked slot */
+uint64_t msh_proof_blob_checksum(const msh_stark* h, int which);
 /* Stark::verify (starks.rs:171-235) on the CPU.  A PARITY MIRROR of the reference's verifier, including what it does NOT bind
  * (INTEGRATION.md "verifier"): 1 accepted, 0 rejected, < 0 malformed. */
 int msh_stark_verify(const msh_stark* h, const uint64_t* constrains, size_t c, size_t N, const uint8_t* arthur, size_t arthur_len, const uint8_t* trace_commit,
@@ -55,6 +66,9 @@ int msh_stark_verify(const msh_stark* h, const uint64_t* constrains, size_t c, s
 size_t msh_proof_serialize(const msh_stark* h, uint8_t* out, size_t cap);
 int msh_proof_parse(const uint8_t* data, size_t len, msh_proof_view* out);
 int msh_stark_verify_mssp(const msh_stark* h, const uint64_t* constrains, size_t c, size_t N, const uint8_t* data, size_t len, int zero_display_empty, char* why, size_t why_cap);
+/* FriProof (fri.rs:17-22) from its MSFP bytes: the compiled twin of the Rust shim's FriProof::from_msfp.  windows = rounds - 1; returns the
+ * number of (window, query) records (windows * nq; the first `cap` are written to `out`) or -1 if the bytes do not parse exactly. */
+int msh_fri_proof_parse(const uint8_t* blob, size_t len, uint32_t e, uint32_t windows, uint32_t nq, msh_fri_query_view* out, size_t cap);
 /* synthetic Fibonacci-AIR trace of the benchmark workload (N x 3 row-major) */
 int msh_fibonacci_rows(uint64_t p, size_t length, size_t steps, uint64_t secret_b, uint64_t pad_seed, uint64_t* out);
 #ifdef __cplusplus

@@ -116,6 +116,14 @@ class Context:
         rc = self.L.ms_num_queries(C.c_int(self.field), C.c_uint64(security_bits), C.c_uint64(blowup), C.c_uint64(steps), C.byref(a), C.byref(b))
         return rc, a.value, b.value
 
+    def arith_selftest(self, op, a, b):
+        """ms_arith_selftest: a (op) b element-wise ON THE DEVICE with the arithmetic class of the NTT tiles (ops: include/ministark.h)."""
+        a, pa = _u64(a)
+        b, pb = _u64(b)
+        out = np.zeros(len(a), dtype=np.uint64)
+        self.check(self.L.ms_arith_selftest(self.h, C.c_int(op), pa, pb, out.ctypes.data_as(_u64p), C.c_size_t(len(a))))
+        return out
+
     def set_stream(self, hip_stream_ptr):
         self.check(self.L.ms_set_stream(self.h, C.c_void_p(hip_stream_ptr)))
 

@@ -153,13 +153,19 @@ struct GLM : GL {
         : "=&v"(s), "=&s"(sv) : "v"(a), "v"(b), "s"(P - 1), "s"(EPS) : "vcc", "scc");
     return s;
   }
+  // r03: the borrow comes out of v_subb_co_u32 as an SGPR pair - no v_cmp_lt_u64: 3 VALU instructions (4).  Two statements: the first
+  // leaves exec alone, so whatever the compiler schedules between them runs under the caller's mask.
   static __device__ __forceinline__ T sub(T a, T b) {
-    u64 d = a - b, sv;
-    asm("v_cmp_lt_u64 vcc, %2, %3\n\t"            // borrow
-        "s_and_saveexec_b64 %1, vcc\n\t"
-        "v_lshl_add_u64 %0, %0, 0, %4\n\t"        // + P
+    u32 d0, d1; u64 bm, sv;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "s_nop 1\n\t"                            // VALU wrote vcc, the next VALU reads it as carry-in: 2 wait states on gfx950
+        "v_subb_co_u32 %1, %2, %4, %6, vcc"        // borrow out -> SGPR pair
+        : "=&v"(d0), "=&v"(d1), "=&s"(bm) : "v"(lo(a)), "v"(hi(a)), "v"(lo(b)), "v"(hi(b)) : "vcc");
+    u64 d = mk(d0, d1);
+    asm("s_and_saveexec_b64 %1, %2\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %3\n\t"        // + P
         "s_mov_b64 exec, %1"
-        : "+v"(d), "=&s"(sv) : "v"(a), "v"(b), "s"(P) : "vcc", "scc");
+        : "+v"(d), "=&s"(sv) : "s"(bm), "s"(P) : "scc");
     return d;
   }
   // A + h * EPS, canonical, for any u64 A and h < 2^32 (the true sum is < 2^65 - 2^33: at most one wrap, and a wrapped sum + EPS < P)
@@ -177,13 +183,17 @@ struct GLM : GL {
   static __device__ __forceinline__ T fold_small(u64 A, u32 h) { return fold(A, h); }
   static __device__ __forceinline__ T mul_x32(T z) { return fold(z << 32, hi(z)); }      // z0 * 2^32 + z1 * EPS
   static __device__ __forceinline__ T mul_x64(T z) {                                      // z0 * EPS - z1
-    const u64 U = (u64)lo(z) * 0xFFFFFFFFu, h1 = (u64)hi(z);
-    u64 r = U - h1, sv;
-    asm("v_cmp_lt_u64 vcc, %2, %3\n\t"
-        "s_and_saveexec_b64 %1, vcc\n\t"
-        "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+    const u64 U = (u64)lo(z) * 0xFFFFFFFFu;
+    u32 d0, d1; u64 bm, sv;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %1, %2, 0, %4, vcc"
+        : "=&v"(d0), "=&v"(d1), "=&s"(bm) : "v"(lo(U)), "v"(hi(U)), "v"(hi(z)) : "vcc");
+    u64 r = mk(d0, d1);
+    asm("s_and_saveexec_b64 %1, %2\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %3\n\t"
         "s_mov_b64 exec, %1"
-        : "+v"(r), "=&s"(sv) : "v"(U), "v"(h1), "s"(P) : "vcc", "scc");
+        : "+v"(r), "=&s"(sv) : "s"(bm), "s"(P) : "scc");
     return r;
   }
   static __device__ __forceinline__ T mul(T a, T b) {
@@ -195,13 +205,8 @@ struct GLM : GL {
         : "=&v"(T0), "=&v"(M), "=&v"(T1), "=&s"(c) : "v"(lo(a)), "v"(hi(a)), "v"(lo(b)), "v"(hi(b)) : "vcc");
     // 128-bit (lo, hi) = T0 + M * 2^32 + T1 * 2^64 + c * 2^96;  r = lo - hi_hi, then + hi_lo * EPS
     u32 L1, H0, H1, R0, R1; u64 bm;
-#ifdef MS_ABL_NONOP   // ablation (timing only: the carry chain breaks the VALU-writes-SGPR -> VALU-reads wait states): what the s_nop cost
-#define MS_NOP1 ""
-#define MS_NOP0 ""
-#else
 #define MS_NOP1 "s_nop 1\n\t"
 #define MS_NOP0 "s_nop 0\n\t"
-#endif
     asm(MS_NOP1                                     // c was written by the VALU instruction that ended the previous statement
         "v_addc_co_u32 %2, vcc, %9, 0, %11\n\t"   // H1 = hi(T1) + c   (no wrap: the product is < 2^128)
         "v_add_co_u32 %0, vcc, %6, %7\n\t"        // L1 = hi(T0) + lo(M)
@@ -246,8 +251,9 @@ struct BB {
   static constexpr int EXT = 4;  // StarkField::Extension = BabyBearFp4 (field.rs:67-70)
   static constexpr u64 NR2 = 11;
   static constexpr int MAX_DIGITS = 10;
-  static MS_HD T add(T a, T b) { u32 s = a + b; if (s >= (u32)P) s -= (u32)P; return s; }
-  static MS_HD T sub(T a, T b) { return a >= b ? a - b : a + (u32)P - b; }
+  // a + b < 2^32 (p < 2^31): the reduced value is the smaller of s and s - p as unsigned numbers (s < p: s - p wraps to something huge); same for a - b
+  static MS_HD T add(T a, T b) { const u32 s = a + b, t = s - (u32)P; return s < t ? s : t; }
+  static MS_HD T sub(T a, T b) { const u32 d = a - b, t = d + (u32)P; return d < t ? d : t; }
   static MS_HD T neg(T a) { return a ? (u32)P - a : 0; }
   // Montgomery reduction (R = 2^32): x * 2^-32 mod p for x < p * 2^32;  MU = -p^-1 mod 2^32
   static constexpr u32 MU = 0x77FFFFFFu;

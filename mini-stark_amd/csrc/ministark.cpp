@@ -4,6 +4,7 @@
 // Compiled with hipcc for gfx950 (libministark.so).  There is no CPU fallback.
 #include "../../include/ministark.h"
 
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -79,7 +80,7 @@ struct CtxBase {
   virtual int fri_round_info(int r, u64* ncoef, u64* D) = 0;
   virtual int fri_round_poly_read(int r, u64* out) = 0;
   virtual int fri_round_codeword_read(int r, u64* out) = 0;
-  virtual int fri_query(const u64* betas, int nq) = 0;
+  virtual int fri_query(const u64* betas, int nq, u8* ext_out, size_t ext_cap, size_t* ext_len) = 0;
   virtual size_t fri_proof_size() const = 0;
   virtual int fri_proof_read(u8* out) = 0;
   virtual int fri_proof_read_async(u8* out) = 0;
@@ -89,6 +90,7 @@ struct CtxBase {
   virtual int ntt(u64* data, size_t n, size_t batch, int inverse) = 0;
   virtual int coset_lde(const u64* coeffs, size_t ncoef, size_t batch, u64 shift, u64* out, size_t L) = 0;
   virtual int bench_lde(size_t blowup, u64 shift) = 0;
+  virtual int arith_selftest(int op, const u64* a, const u64* b, u64* out, size_t n) = 0;
   virtual int profile_begin() = 0;
   virtual int profile_end(char* out, size_t cap) = 0;
 };
@@ -148,21 +150,24 @@ template <class F> struct Ctx : CtxBase {
     if (rccl_comm) { msrt::sync(stream); msrt::Rccl::get().comm_destroy(rccl_comm); rccl_comm = nullptr; }
     rccl_send.release(); rccl_recv.release();
   }
+  void unshard() { sh_rank = 0; sh_world = 1; xs = xr = nullptr; xcap = 0; xfn = nullptr; xuser = nullptr; have_lde = false; nrounds_done = 0; blob_size = 0; }
   int set_shard_rccl(int rank, int world, const u8* unique_id, size_t cap) override {
     if (world < 1 || !is_pow2((u64)world) || rank < 0 || rank >= world) return fail(MS_ERR_ARG, "set_shard_rccl: world must be a power of two and 0 <= rank < world");
+    // the old communicator and buffers go first; until the new ones are complete the context is UNSHARDED, so that a failure below
+    // (no unique id, librccl missing, out of memory, ncclCommInitRank) cannot leave sh_world > 1 over freed buffers / a null callback
     drop_rccl();
-    if (world == 1) return set_shard(0, 1, nullptr, nullptr, 0, nullptr, nullptr);
+    unshard();
+    if (world == 1) return MS_OK;
     if (!unique_id || cap < 4096) return fail(MS_ERR_ARG, "set_shard_rccl: unique id / buffer capacity missing");
     msrt::Rccl& R = msrt::Rccl::get();
     if (R.load()) return fail(MS_ERR_HIP, "RCCL is not available (librccl.so could not be loaded; MS_RCCL_LIB names it)");
-    if (rccl_send.ensure(cap) || rccl_recv.ensure(cap)) return fail(MS_ERR_NOMEM, "exchange buffers");
+    if (rccl_send.ensure(cap) || rccl_recv.ensure(cap)) { drop_rccl(); return fail(MS_ERR_NOMEM, "exchange buffers"); }
     msrt::Rccl::UniqueId id; memcpy(id.internal, unique_id, sizeof id.internal);
     void* comm = nullptr;
     const int e = R.comm_init_rank(&comm, world, id, rank);
-    if (e || !comm) { err = std::string("ncclCommInitRank failed: ") + (R.err_string ? R.err_string(e) : "?"); return MS_ERR_HIP; }
+    if (e || !comm) { drop_rccl(); err = std::string("ncclCommInitRank failed: ") + (R.err_string ? R.err_string(e) : "?"); return MS_ERR_HIP; }
     rccl_comm = comm;
-    sh_rank = rank; sh_world = world; xs = rccl_send.as<u8>(); xr = rccl_recv.as<u8>(); xcap = cap; xfn = nullptr; xuser = nullptr;
-    have_lde = false; nrounds_done = 0; blob_size = 0;
+    sh_rank = rank; sh_world = world; xs = rccl_send.as<u8>(); xr = rccl_recv.as<u8>(); xcap = cap;
     return MS_OK;
   }
   // The four collectives on a one-rank communicator (send/recv to self, all-gather, both all-reduces) with known payloads:
@@ -222,7 +227,16 @@ template <class F> struct Ctx : CtxBase {
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
   double next_bytes = 0;  // algorithmic bytes attributed to the next launch
-  int next_sub = 0;       // NTT pass variant of the next launch: K | 16*(TH==512) | 32*generic | 64*inverse
+  int next_sub = 0;       // NTT pass template instance of the next launch: index into ntt_names (the kernel names rocprofv3 reports)
+  std::vector<std::string> ntt_names{std::string("?")};
+  void name_next(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+    if (!prof_on) return;
+    char buf[200]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    for (size_t i = 0; i < ntt_names.size(); i++) if (ntt_names[i] == buf) { next_sub = (int)i; return; }
+    ntt_names.push_back(buf); next_sub = (int)ntt_names.size() - 1;
+  }
+  static const char* fname() { return F::ID == 0 ? "GL" : "BB"; }
+  template <class A> static const char* aname() { return std::is_same<A, GLM>::value ? "GLM" : (std::is_same<A, GLT>::value ? "GLT" : (std::is_same<A, GL>::value ? "GL" : "BB")); }
   template <class K> int run_coop(int kid, unsigned gx, int threads, size_t lds, const typename K::Params& p) {
     if (gx == 0) return 0;
     if (!prof_on) return msrt::launch_coop<K>(stream, gx, 1, threads, lds, p);
@@ -269,13 +283,8 @@ template <class F> struct Ctx : CtxBase {
     j += ", \"ntt_pass_variants\": {";
     bool first = true;
     for (auto& kv : sub_ms) {
-      const int sub = kv.first; char name[160], buf[320];
-      const char* fld = F::ID == 0 ? "GL" : "BB";
-      if (sub & 16384) snprintf(name, sizeof name, "msntt::RegPassKernel<%s, %s, %s, %d>", fld, F::ID == 0 ? "GLM" : "BB", (sub & 64) ? "true" : "false", sub & 15);
-      else if (sub & 128) snprintf(name, sizeof name, "msntt::PassKernel2<%s, %s, %s, %d, %d, %d, %d, %d>", fld, (sub & 2048) ? "GLM" : (F::ID == 0 ? "GLT" : "BB"), (sub & 64) ? "true" : "false",
-                              sub & 15, (sub >> 8) & 7, (sub & 2048) ? (((sub >> 8) & 7) == 4 ? 1024 : ((sub & 15) == 8 ? 256 : 512)) : 256, (sub & 2048) ? 3 : 2, (sub >> 12) & 3);
-      else if (sub & 32) snprintf(name, sizeof name, "msntt::PassKernel<%s, %s, %d>", fld, (sub & 64) ? "true" : "false", (sub & 16) ? 512 : 256);
-      else snprintf(name, sizeof name, "msntt::PassKernelK<%s, %s, %d, %d>", fld, (sub & 64) ? "true" : "false", sub & 15, (sub & 16) ? 512 : 256);
+      const int sub = kv.first; char buf[420];
+      const char* name = ntt_names[(size_t)sub < ntt_names.size() ? sub : 0].c_str();
       snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"alg_bytes\": %.0f}", first ? "" : ", ", name, sub_cnt[sub], kv.second, sub_by[sub]);
       j += buf; first = false;
     }
@@ -296,7 +305,7 @@ template <class F> struct Ctx : CtxBase {
   std::map<int, Plan*> plans;  // key = (log_n*4 + log_pad)*2 + inverse
   DevBuf ntt_scratch;
   int ntt_kmax = 9;            // largest tile (log2 rows) of a multi-pass plan; MS_NTT_KMAX overrides (tuning)
-  int ntt_v2 = 1, ntt_v2_min = 14, ntt_v2_maxpass = 2, ntt_v2_sub3 = 1, ntt_v2_wide = 0, ntt_v2_regpass = 1;   // MS_NTT_V2=0: round-1 kernels only (A/B); transforms of at least 2^MS_NTT_V2_MIN points use the two-sub-round tiles
+  int ntt_v2 = 1, ntt_v2_min = 14, ntt_v2_maxpass = 2, ntt_v2_sub3 = 1, ntt_v2_regpass = 1;   // MS_NTT_V2=0: round-1 kernels only (A/B); transforms of at least 2^MS_NTT_V2_MIN points use the two-sub-round tiles
   int ntt_colbatch = 0, ntt_mall_mib = 96;    // MS_NTT_COLBATCH: columns per chunk of a multi-pass transform (0: all; -1: as many as keep a chunk within MS_NTT_MALL_MIB); see ntt_run
   int ntt_maxpad = msntt::MAX_LOG_PAD, ntt_maxrho = msntt::MAX_LOG_RHO, ntt_th512 = 1, ntt_fast = 1, ntt_fast_min = 22, ntt_fast_max = 24;  // tuning knobs (MS_NTT_MAXPAD / MS_NTT_MAXRHO / MS_NTT_TH512)
 
@@ -310,8 +319,8 @@ template <class F> struct Ctx : CtxBase {
     pl->log_n = log_n;
     const int v2_lc = (F::ID == 0) ? 3 : 4;   // 64-byte tile rows: 8 Goldilocks / 16 BabyBear columns
     bool use_v2 = false;
-    // BabyBear keeps the round-1 tiles unless MS_NTT_V2=2: its 2-sub-round tiles measured slower (LDE 6 x 2^20 -> 2^23: 0.62 ms vs 0.50 ms)
-    if ((F::ID == 0 ? ntt_v2 >= 1 : ntt_v2 >= 2) && log_n >= ntt_v2_min && log_n > msntt::MAX_LOG_R && (log_pad == 0 || log_pad == 3)) {
+    // both fields (r03: BabyBear too - LDE 6 x 2^20 -> 2^23 0.505 ms on the round-1 tiles, 0.415 ms on these with two sub-rounds; MS_NTT_V2=0: round-1 tiles)
+    if (ntt_v2 >= 1 && log_n >= ntt_v2_min && log_n > msntt::MAX_LOG_R && (log_pad == 0 || log_pad == 3)) {
       // passes of up to 2^10 rows; a blowup-8 evaluation starts behind the virtual radix-8 zero-padding pass (8 tile columns = its 8 cosets)
       const int m = log_n - log_pad, P = (m + 9) / 10;
       const int kb = (ntt_v2_regpass == 2) ? 7 : 10;   // MS_NTT_V2_REGPASS=2 (tests): the same plan shape on 2^7-row tiles, so that 2^15..2^19 points exercise every register radix
@@ -328,7 +337,6 @@ template <class F> struct Ctx : CtxBase {
         pl->log_rho = 0; pl->log_r0 = log_pad; pl->npass = P;
         for (int i = 0; i < P; i++) {
           pl->K[i] = m / P + (i < m % P ? 1 : 0); pl->LC[i] = (i == 0 && log_pad) ? 3 : v2_lc; pl->v2[i] = true;
-          if (F::ID == 0 && ntt_v2_wide && i > 0 && pl->K[i] == 10) pl->LC[i] = 4;   // later passes: 128-byte runs, one 1024-thread workgroup per CU
         }
       }
     }
@@ -416,41 +424,36 @@ template <class F> struct Ctx : CtxBase {
   template <bool INV, int K, int TH>
   int launch_fast(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
     typedef msntt::PassKernelK<F, INV, K, TH> KK;
-    next_sub = K | (TH == 512 ? 16 : 0) | (INV ? 64 : 0);
+    name_next("msntt::PassKernelK<%s, %s, %d, %d>", fname(), INV ? "true" : "false", K, TH);
     return run<KK>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, TH, KK::lds_bytes(), pp);
   }
-#ifndef MS_ARITH3
-#define MS_ARITH3 GLM   // arithmetic class of the 512-thread three-sub-round tiles (A/B builds: -DMS_ARITH3=GLT)
-#endif
+  // PassKernel2 instance for a pass of 2^K rows x 2^LC columns in MODE (ntt.hpp): tile shape -> threads, sub-rounds, arithmetic class
+  template <class KK> int launch_v2i(const msntt::PassParams<F>& pp, unsigned grid, int nsub, int mode, int k, int lc) {
+    if (!KK::applicable(pp)) return 998;   // NTT plan / PassKernel2 mismatch (a bug, not a runtime condition)
+    name_next("msntt::PassKernel2<%s, %s, %s, %d, %d, %d, %d, %d>", fname(), aname<typename KK::Arith>(), KK::INVERSE ? "true" : "false", k, lc, KK::THREADS, nsub, mode);
+    return run_coop<KK>(K_NTT_PASS, grid, KK::THREADS, KK::lds_bytes(), pp);
+  }
   template <bool INV, int K, int LC, int MODE>
   int launch_v2m(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
-    if constexpr (F::ID == 0 && K == 10 && LC == 4 && MODE == 1) {   // 16 columns x 1024 rows: 1024 threads, one workgroup per CU
-      typedef msntt::PassKernel2<F, GLM, INV, K, LC, 1024, 3, MODE> KK;
-      if (!KK::applicable(pp)) return 998;
-      next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | 2048 | (MODE << 12);
-      return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch) > 256 ? 256 : coop_grid(tiles * batch), 1024, KK::lds_bytes(), pp);
-    }
     if constexpr (F::ID == 0 && (K == 8 || K == 9) && LC == 3) {
       if (ntt_v2_sub3) {   // smaller tiles of the three-pass plans: 8 elements per thread, radix 8 x 8 x 4 (or 8), many workgroups per CU
         constexpr int TH3 = (K == 8) ? 256 : 512;
-        typedef msntt::PassKernel2<F, GLM, INV, K, LC, TH3, 3, MODE> KK;
-        if (!KK::applicable(pp)) return 998;
-        next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | 2048 | (MODE << 12);
-        return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch, K == 8 ? 8 : 4), TH3, KK::lds_bytes(), pp);
+        return launch_v2i<msntt::PassKernel2<F, GLM, INV, K, LC, TH3, 3, MODE>>(pp, coop_grid(tiles * batch, K == 8 ? 8 : 4), 3, MODE, K, LC);
       }
     }
     if constexpr (F::ID == 0 && K == 10 && LC == 3) {
-      if (ntt_v2_sub3) {   // 512 threads, three sub-rounds, exec-masked arithmetic: 16 waves per CU
-        typedef msntt::PassKernel2<F, MS_ARITH3, INV, K, LC, 512, 3, MODE> KK;
-        if (!KK::applicable(pp)) return 998;
-        next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | 2048 | (MODE << 12);
-        return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch), 512, KK::lds_bytes(), pp);
+      if (ntt_v2_sub3)     // 512 threads, three sub-rounds, exec-masked arithmetic: 16 waves per CU
+        return launch_v2i<msntt::PassKernel2<F, GLM, INV, K, LC, 512, 3, MODE>>(pp, coop_grid(tiles * batch), 3, MODE, K, LC);
+    }
+    if constexpr (F::ID == 1 && K == 10) {
+      // BabyBear, 64 KiB tiles of 16 columns (MODE 0 / 1) or 32 KiB tiles of the 8 cosets (MODE 2): three sub-rounds (radix 16 x 8 x 8) with the
+      // fused tail - 512 threads x 32 elements, resp. 256 threads x 32 elements and four workgroups per CU: 16 waves per CU either way
+      if (ntt_v2_sub3) {
+        constexpr int THB = (LC == 4) ? 512 : 256;
+        return launch_v2i<msntt::PassKernel2<F, BB, INV, K, LC, THB, 3, MODE>>(pp, coop_grid(tiles * batch, LC == 4 ? 2 : 4), 3, MODE, K, LC);
       }
     }
-    typedef msntt::PassKernel2<F, typename msntt::NttArith<F>::type, INV, K, LC, 256, 2, MODE> KK;
-    if (!KK::applicable(pp)) return 998;   // NTT plan / PassKernel2 mismatch (a bug, not a runtime condition)
-    next_sub = K | (LC << 8) | 128 | (INV ? 64 : 0) | (MODE << 12);
-    return run_coop<KK>(K_NTT_PASS, coop_grid(tiles * batch), 256, KK::lds_bytes(), pp);
+    return launch_v2i<msntt::PassKernel2<F, typename msntt::NttArith<F>::type, INV, K, LC, 256, 2, MODE>>(pp, coop_grid(tiles * batch), 2, MODE, K, LC);
   }
   // persistent grid of the cooperative pass kernels: two workgroups per CU (their 72-80 KiB of LDS), a multiple of 8 (XCD-aware tile walk)
   int ntt_coop_wgs = 512;
@@ -475,7 +478,7 @@ template <class F> struct Ctx : CtxBase {
   int launch_reg(const msntt::PassParams<F>& pp, size_t batch) {
     typedef msntt::RegPassKernel<F, typename std::conditional<F::ID == 0, GLM, F>::type, INV, K> KK;
     if (!KK::applicable(pp)) return 995;
-    next_sub = K | 16384 | (INV ? 64 : 0);
+    name_next("msntt::RegPassKernel<%s, %s, %s, %d>", fname(), F::ID == 0 ? "GLM" : "BB", INV ? "true" : "false", K);
     return run<KK>(K_NTT_PASS, KK::grid(pp), (unsigned)batch, KK::THREADS, 0, pp);
   }
   template <bool INV>
@@ -491,7 +494,7 @@ template <class F> struct Ctx : CtxBase {
       }
     }
     if (v2) {
-      if constexpr (F::ID == 0) return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : (pp.log_r == 10 && pp.log_C == 4 ? launch_v2<INV, 10, 4>(pp, tiles, batch) : 997);
+      if constexpr (F::ID == 0) return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : 997;
       else return pp.log_C == 3 ? launch_v2k<INV, 3>(pp, tiles, batch) : launch_v2k<INV, 4>(pp, tiles, batch);
     }
     // compile-time specialised tiles for the large transforms (no virtual pass, 16 columns)
@@ -505,9 +508,9 @@ template <class F> struct Ctx : CtxBase {
       }
     }
     const size_t lds = msntt::PassKernel<F, INV, 256>::lds_bytes(pp.log_r, pp.log_C, pp.log_Rp, pp.last != 0);
-    next_sub = 32 | (INV ? 64 : 0);
-    if (ntt_th512 && pp.log_r >= 9 && pp.log_C == msntt::TILE_LOG_C) {  // 8192-element tiles: 16 elements per thread
-      next_sub |= 16;
+    const bool th512 = ntt_th512 && pp.log_r >= 9 && pp.log_C == msntt::TILE_LOG_C;   // 8192-element tiles: 16 elements per thread
+    name_next("msntt::PassKernel<%s, %s, %d>", fname(), INV ? "true" : "false", th512 ? 512 : 256);
+    if (th512) {
       return run<msntt::PassKernel<F, INV, 512>>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, 512, lds, pp);
     }
     return run<msntt::PassKernel<F, INV, 256>>(K_NTT_PASS, (unsigned)tiles, (unsigned)batch, 256, lds, pp);
@@ -750,7 +753,6 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
     if (const char* e = getenv("MS_NTT_V2")) ntt_v2 = atoi(e);
     if (const char* e = getenv("MS_NTT_V2_SUB3")) ntt_v2_sub3 = atoi(e);
-    if (const char* e = getenv("MS_NTT_V2_WIDE")) ntt_v2_wide = atoi(e);
     if (const char* e = getenv("MS_NTT_V2_REGPASS")) ntt_v2_regpass = atoi(e);
     if (const char* e = getenv("MS_NTT_COOP_WGS")) { int v = atoi(e); if (v >= 8 && v <= 65536) ntt_coop_wgs = v & ~7; }
     if (const char* e = getenv("MS_NTT_V2_MAXPASS")) { int v = atoi(e); if (v >= 1 && v <= 4) ntt_v2_maxpass = v; }
@@ -1021,6 +1023,24 @@ template <class F> struct Ctx : CtxBase {
   int bench_lde(size_t blowup_, u64 shift) override {
     if (!have_polys) return fail(MS_ERR_STATE, "bench_lde before interpolate");
     return lde_compute(blowup_, shift);
+  }
+  int arith_selftest(int op, const u64* a, const u64* b, u64* out, size_t n) override {
+    if (!a || !b || !out || op < 0 || op > 7 || (F::ID != 0 && op > 3)) return fail(MS_ERR_ARG, "arith_selftest: bad operation / null argument");
+    if (!n) return MS_OK;
+    if (!canonical(a, n) || (op < 6 && !canonical(b, n))) return fail(MS_ERR_ARG, "operand not canonical");
+    DevBuf d;
+    if (d.ensure(3 * n * 8)) return fail(MS_ERR_NOMEM, "arith_selftest");
+    typedef typename std::conditional<F::ID == 0, GLM, F>::type A;
+    typedef mspoly::ArithKernel<F, A> AK;
+    int e = msrt::h2d(d.p, a, n * 8, stream);
+    if (!e) e = msrt::h2d(d.as<u64>() + n, b, n * 8, stream);
+    if (!e) e = msrt::sync(stream);
+    typename AK::Params ap{d.as<u64>(), d.as<u64>() + n, d.as<u64>() + 2 * n, n, op};
+    if (!e) e = run<AK>(K_IO, grid1(n, AK::THREADS), 1, AK::THREADS, 0, ap);
+    if (!e) e = msrt::d2h(out, d.as<u64>() + 2 * n, n * 8, stream);
+    if (!e) e = msrt::sync(stream);
+    d.release();
+    return e ? fail_rt(e, "arith_selftest") : MS_OK;
   }
   int lde_read(u64* out) override {
     if (!have_lde || !out) return fail(MS_ERR_STATE, "lde_read");
@@ -1325,7 +1345,11 @@ template <class F> struct Ctx : CtxBase {
   // ------------------------------------------------------------------ fri.rs:115-189
   // The whole query phase is a fixed handful of batched launches, whatever the number of
   // rounds and queries: every per-(window, query) step is a job in a device-side table.
-  int fri_query(const u64* betas, int nq) override {
+  // ext_out != nullptr (ms_fri_query_into): the query-phase kernels write the MSFP blob straight into the caller's buffer - page-locked host
+  // memory (ms_pinned_alloc; hipHostMalloc memory is mapped into the device's address space) or device memory - instead of d_blob:
+  // no read-back copy afterwards (r02: the runtime executed most of the 64 MiB read-back as shader copies, -15 % on the I/O-inclusive rate)
+  bool blob_external = false;
+  int fri_query(const u64* betas, int nq, u8* ext_out, size_t ext_cap, size_t* ext_len) override {
     if (nrounds_done != fri_rounds || fri_rounds == 0) return fail(MS_ERR_STATE, "fri_query before the commit phase finished");
     if (!betas || nq < 1) return fail(MS_ERR_ARG, "fri_query");
     const size_t W = fri_rounds - 1;  // windows (previous, round); round W is only evaluated
@@ -1346,16 +1370,20 @@ template <class F> struct Ctx : CtxBase {
       }
     }
     blob_size = 0;
+    if (ext_len) *ext_len = pos;
+    if (ext_out && ext_cap == 0) return MS_OK;   // size query
+    if (ext_out && ext_cap < pos) return fail(MS_ERR_ARG, "ms_fri_query_into: buffer too small (the size needed is in *len)");
     // ---- device buffers
     size_t sh_elems = 0;
     for (size_t i = 0; i <= W; i++) sh_elems += (size_t)nq * (sh_scratch_elems((rounds[i]->ncoef + 1) / 2) + sh_scratch_elems(rounds[i]->ncoef / 2));
     const size_t n_h0 = (W + 1) * nq * 2 * E, n_tg = (W ? W : 1) * 2 * nq * E;
-    if (copy_pending) {   // an asynchronous read-back of the previous proof: finish it before the blob moves, order it before the blob is rewritten
+    if (copy_pending && !ext_out) {   // an asynchronous read-back of the previous proof: finish it before the blob moves, order it before the blob is rewritten
       if (pos + 8 > d_blob.cap) RQ(fri_proof_wait()); else CK(msrt::stream_wait_event(stream, ev_copy));
     }
-    if (d_blob.ensure(pos + 8) || d_sh.ensure(sh_elems * sizeof(T)) || d_targets.ensure((n_h0 + n_tg) * sizeof(T)) || d_idx.ensure((W ? W : 1) * nq * 2 * 8))
+    if ((!ext_out && d_blob.ensure(pos + 8)) || d_sh.ensure(sh_elems * sizeof(T)) || d_targets.ensure((n_h0 + n_tg) * sizeof(T)) || d_idx.ensure((W ? W : 1) * nq * 2 * 8))
       return fail(MS_ERR_NOMEM, "query buffers");
-    u8* blob = d_blob.as<u8>();
+    u8* blob = ext_out ? ext_out : d_blob.as<u8>();
+    blob_external = ext_out != nullptr;
     T* d_h0 = d_targets.as<T>();
     T* d_tg = d_h0 + n_h0;
     unsigned long long* d_ix = d_idx.as<unsigned long long>();
@@ -1501,6 +1529,7 @@ template <class F> struct Ctx : CtxBase {
   size_t fri_proof_size() const override { return blob_size; }
   int fri_proof_read(u8* out) override {
     if (!blob_size || !out) return fail(MS_ERR_STATE, "no FRI proof");
+    if (blob_external) return fail(MS_ERR_STATE, "the FRI proof was written to the caller's buffer (ms_fri_query_into)");
     RQ(fri_proof_wait());
     CK(msrt::d2h(out, d_blob.p, blob_size, stream));
     CK(msrt::sync(stream));
@@ -1511,6 +1540,7 @@ template <class F> struct Ctx : CtxBase {
   msrt::Stream* copy_stream = nullptr; msrt::Event* ev_blob = nullptr; msrt::Event* ev_copy = nullptr; bool copy_pending = false;
   int fri_proof_read_async(u8* out) override {
     if (!blob_size || !out) return fail(MS_ERR_STATE, "no FRI proof");
+    if (blob_external) return fail(MS_ERR_STATE, "the FRI proof was written to the caller's buffer (ms_fri_query_into)");
     if (!copy_stream) { CK(msrt::stream_create(&copy_stream)); CK(msrt::event_create(&ev_blob)); CK(msrt::event_create(&ev_copy)); }
     CK(msrt::event_record(ev_blob, stream));
     CK(msrt::stream_wait_event(copy_stream, ev_blob));
@@ -1726,7 +1756,13 @@ int ms_fri_fold_commit(ms_ctx* ctx, const uint64_t* a, uint8_t root[32]) { CTX_O
 int ms_fri_round_info(ms_ctx* ctx, int r, uint64_t* nc, uint64_t* D) { CTX_OR_FAIL; return B(ctx)->fri_round_info(r, nc, D); }
 int ms_fri_round_poly_read(ms_ctx* ctx, int r, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->fri_round_poly_read(r, out); }
 int ms_fri_round_codeword_read(ms_ctx* ctx, int r, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->fri_round_codeword_read(r, out); }
-int ms_fri_query(ms_ctx* ctx, const uint64_t* betas, int nq) { CTX_OR_FAIL; return B(ctx)->fri_query(betas, nq); }
+int ms_fri_query(ms_ctx* ctx, const uint64_t* betas, int nq) { CTX_OR_FAIL; return B(ctx)->fri_query(betas, nq, nullptr, 0, nullptr); }
+int ms_fri_query_into(ms_ctx* ctx, const uint64_t* betas, int nq, uint8_t* out, size_t cap, size_t* len) {
+  CTX_OR_FAIL;
+  if (!out && cap) return MS_ERR_ARG;
+  static uint8_t probe;   // out == NULL, cap == 0: size query only (*len), nothing is computed
+  return B(ctx)->fri_query(betas, nq, out ? out : &probe, out ? cap : 0, len);
+}
 size_t ms_fri_proof_size(const ms_ctx* ctx) { return ctx ? B(ctx)->fri_proof_size() : 0; }
 int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out) { CTX_OR_FAIL; return B(ctx)->fri_proof_read(out); }
 int ms_fri_proof_read_async(ms_ctx* ctx, uint8_t* out) { CTX_OR_FAIL; return B(ctx)->fri_proof_read_async(out); }
@@ -1740,6 +1776,7 @@ int ms_merkle_prove(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext
 int ms_ntt(ms_ctx* ctx, uint64_t* data, size_t n, size_t batch, int inverse) { CTX_OR_FAIL; return B(ctx)->ntt(data, n, batch, inverse); }
 int ms_coset_lde(ms_ctx* ctx, const uint64_t* c, size_t ncoef, size_t batch, uint64_t shift, uint64_t* out, size_t L) { CTX_OR_FAIL; return B(ctx)->coset_lde(c, ncoef, batch, shift, out, L); }
 int ms_bench_lde(ms_ctx* ctx, size_t blowup, uint64_t shift) { CTX_OR_FAIL; return B(ctx)->bench_lde(blowup, shift); }
+int ms_arith_selftest(ms_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { CTX_OR_FAIL; return B(ctx)->arith_selftest(op, a, b, out, n); }
 int ms_profile_begin(ms_ctx* ctx) { CTX_OR_FAIL; return B(ctx)->profile_begin(); }
 int ms_profile_end(ms_ctx* ctx, char* json_out, size_t cap) { CTX_OR_FAIL; return B(ctx)->profile_end(json_out, cap); }
 

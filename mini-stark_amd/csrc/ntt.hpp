@@ -436,45 +436,51 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
 };
 
 // ---------------------------------------------------------------------------------------------
-// PassKernel2: the large-transform pass of round 2.  A tile of 2^K rows x 2^LC columns (GL: 2^10 x 8 = 64 KiB, two workgroups per
-// CU) is transformed by NSUB register sub-rounds, so that a 2^20-point transform (and, behind the virtual radix-8 zero-padding
-// pass, the 2^23-point LDE of 2^20 coefficients) is TWO HBM passes of ten butterfly stages instead of three of eight.
-// Measured background (tools/ntt_lab.hip, profiles/r02_ntt_lab.log): these kernels are bound by the NUMBER of VALU instructions
-// (3.3-3.6 issue cycles each whatever the opcode) and by how many waves hide each other's stalls:
-//   NSUB = 2, 256 threads, arithmetic class GLT: radix-32 x radix-32 per thread, one twiddle multiplication inside the tile,
-//             compiler-scheduled sign-bit arithmetic (tolerates the 2 waves per SIMD the 64 KiB tile leaves)
+// PassKernel2: the large-transform pass.  A tile of 2^K rows x 2^LC columns (GL: 2^10 x 8 = 64 KiB, two workgroups per CU) is
+// transformed by NSUB register sub-rounds, so that a 2^20-point transform (and, behind the virtual radix-8 zero-padding pass, the
+// 2^23-point LDE of 2^20 coefficients) is TWO HBM passes of ten butterfly stages instead of three of eight.
+// These kernels are bound by the NUMBER of VALU instructions they issue (3.3-3.6 issue cycles each whatever the opcode:
+// tools/ntt_lab.hip) and by how many waves hide each other's stalls:
+//   NSUB = 2, 256 threads: radix-32 x radix-32 per thread, one twiddle multiplication inside the tile, compiler-scheduled arithmetic
+//             (tolerates the 2 waves per SIMD a 64 KiB tile leaves)
 //   NSUB = 3, 512 threads, arithmetic class GLM: radix-16 x 8 x 8, 16 waves per CU - the occupancy the exec-masked arithmetic
 //             (7.8 instead of 11.7 VALU instructions per element-stage) needs; one more twiddle multiplication and LDS round trip.
 // Global access is 16 bytes per lane (global_load/store_dwordx4: VEC = 2 Goldilocks / 4 BabyBear elements), a tile row is one
-// 64-byte run.  LDS: element (row, c) at prow(row)*C + c with prow(row) = row ^ ((row >> BL) & 3), BL = bits of the last digit:
+// 16*LPR-byte run.  LDS: element (row, c) at prow(row)*C + c with prow(row) = row ^ ((row >> BL) & 3), BL = bits of the last digit:
 // the XOR spreads the four row groups a half-wave touches in the last sub-round over all banks (no padding, 16-byte alignment kept),
 // and permutes rows only inside aligned groups of four, which the other access patterns (lanes over consecutive rows x columns)
-// do not notice.  The w_r table (sub-round twiddles) and the per-row store twiddles share one LDS region for Goldilocks.
-// Cases (same index algebra as PassKernel above):
-//   log_r0 == 0, log_Rp == 0   first pass of a plain transform: transposed store, twiddle w_n^(i_new * f)
-//   log_r0 == 0, log_Rp >= LC  later pass: 64-byte output runs, one twiddle per tile row (none in the last pass)
-//   log_r0 == LC (GL: 3)       first pass behind the virtual zero-padding pass: the C columns of a tile are the r0 cosets of ONE
-//                              coefficient index, the tile's output is one contiguous block of r0 * r elements
+// do not notice.
+// MODE (compile time: each instance carries ONE load path and ONE store path; same index algebra as PassKernel above):
+//   0  log_r0 == 0, log_Rp == 0   first pass of a plain transform: rows in, transposed store, twiddle w_n^(i_new * f)
+//   1  log_r0 == 0, log_Rp >= LC  later pass: rows in, 16*LPR-byte output runs, one twiddle per tile row (none in the last pass)
+//   2  log_r0 == LC               first pass behind the virtual zero-padding pass: the C columns of a tile are the r0 cosets of ONE
+//                                 coefficient index; coefficients staged through LDS one tile ahead, the tile's output is one
+//                                 contiguous block of r0 * r elements
+// What was tried on these tiles and lost (cross-tile register prefetch, LDS-DMA prefetch with a counted vmcnt, the expanded
+// coefficients kept in registers for the first sub-round, 16-column 1024-thread tiles, the timing-only ablation branches) lives in
+// the round-2 history of this file and in profiles/r02_*.log, not in the product kernel.
 template <int K, int NSUB> struct Digits2 {
   // digit sizes, top digit first: NSUB == 2: (ceil(K/2), floor(K/2)); NSUB == 3: last = K/3, middle = (K - last)/2, top = the rest
   // (10: 4,3,3   9: 3,3,3   8: 3,3,2   7: 3,2,2)
   static constexpr int bits(int s) { return NSUB == 2 ? (s == 0 ? (K + 1) / 2 : K / 2) : (s == 2 ? K / 3 : (s == 1 ? (K - K / 3) / 2 : K - K / 3 - (K - K / 3) / 2)); }
   static constexpr int slo(int s) { int d = 0; for (int t = 0; t <= s; t++) d += bits(t); return K - d; }
 };
-// MODE (compile time, so that each instance carries one load and one store path): 0 first pass of a plain transform,
-// 1 later pass, 2 first pass behind the virtual zero-padding pass
 template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE> struct PassKernel2 {
   typedef typename F::T T;
   typedef PassParams<F> Params;
   typedef Digits2<K, NSUB> DG;
+  typedef A Arith;
+  static constexpr bool INVERSE = INV;
   static constexpr int THREADS = TH;
   static constexpr int R = 1 << K, C = 1 << LC;
   static constexpr int BL = DG::bits(NSUB - 1);
   static constexpr int VEC = 16 / (int)sizeof(T), LPR = C / VEC, RPS = TH / LPR, SWEEPS = R / RPS;  // lanes per row, rows per sweep
-  static constexpr int MIN_WAVES = (TH >= 512) ? 4 : 2;    // waves per SIMD the register allocator must leave room for (16 waves per CU: 2 x 512 or 1 x 1024 threads)
+  // waves per SIMD the register allocator must leave room for: 16 waves per CU = 2 x 512 threads on 64 KiB tiles, or 4 x 256 threads on BabyBear's 32 KiB tiles behind the virtual pass
+  static constexpr int MIN_WAVES = (TH >= 512 || (sizeof(T) == 4 && K == 10 && LC == 3 && NSUB == 3)) ? 4 : 2;
   static_assert(K >= 7 && K <= 10 && DG::bits(0) <= 5 && BL >= 2 && C % VEC == 0 && TH % LPR == 0 && R % RPS == 0 && (NSUB == 2 || NSUB == 3), "unsupported tile");
   static_assert(NSUB == 2 || DG::bits(1) >= 2, "middle digit");
-  typedef T V16 __attribute__((vector_size(16)));   // one 16-byte global / LDS access; a native vector, so that prefetched rows stay in registers
+  static_assert(MODE >= 0 && MODE <= 2, "MODE");
+  typedef T V16 __attribute__((vector_size(16)));   // one 16-byte global / LDS access
 
   // tile | w_r [R] | store twiddle of every tile row [R] (filled in the load phase, while the tile's global loads are in flight)
   static MS_HD size_t lds_bytes() { return ((size_t)R * C + 2 * R) * sizeof(T); }
@@ -533,164 +539,64 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     if constexpr (J + 1 < NJ) sub_items<SR, J + 1, MG>(tid, tile, w);
   }
 
-  // first sub-round whose 2^B0 inputs are already in the lane's registers (FUSE_HEAD): x[t] = element (row lo + t * 2^SLO(0), column c)
-  template <bool MG> static MS_DEV void sub0_regs(T (&x)[1 << DG::bits(0)], int tid, T* tile, const T* w) {
-    constexpr int B = DG::bits(0), SLO = DG::slo(0);   // FUSE_HEAD guarantees SLO >= BL + 2: the row swizzle does not touch this digit
-    const int c = tid & (C - 1), lo = tid >> LC;                     // one item per lane: g = lo (the top digit is the only one above)
-    T* base = tile + ((lo ^ ((lo >> BL) & 3)) * C + c);
-    dif_regs<A, INV, B>(x, w, K);
-#pragma unroll
-    for (int e = 0; e < (1 << B); e++) {
-      T v = x[bitrev(e, B)];
-      if (e != 0) v = A::mul_tw(v, MG ? w[(e << SLO) + lo] : w[(e * lo) << (K - SLO - B)]);
-      base[(e << SLO) * C] = v;
-    }
-  }
-  // ---- cooperative, persistent form: a workgroup walks tiles g = bx, bx + nbx, ... of the nbatch * tiles of the launch, and the
-  // global loads of its NEXT tile are issued into registers right after the first sub-round, so that they are in flight during the
-  // remaining sub-rounds and the store of the current one.  Measured before this change (profiles/r02_*): with a load burst at the
-  // start of every tile and two workgroups per CU the waves sat in s_waitcnt / s_barrier 60 % of the time and the CU kept ~17 KiB of
-  // loads in flight on average - a latency bound at 2.9 TB/s with the VALU 15 % busy.
-  // Cross-tile prefetch: measured on MI355X (r02) it does NOT pay - the 32 registers it holds across the sub-rounds push the kernel over
-  // its 128-VGPR budget (spills, whose scratch traffic shares the vector-memory counter with the prefetch), and with it fitted (later
-  // passes: 13 spills, all outside the prefetch window) the pass still took 323 us instead of 298: the memory path alone (no
-  // sub-rounds) needs 220 us, the arithmetic alone 187 us, and two workgroups per CU already overlap most of the two.
-#ifndef MS_NTT_PREFETCH
-#define MS_NTT_PREFETCH 0
-#endif
-#ifndef MS_NTT_XCD_LATER
-#define MS_NTT_XCD_LATER 1
-#endif
-#ifndef MS_NTT_STAGE_SRC
-#define MS_NTT_STAGE_SRC 1
-#endif
-#ifndef MS_NTT_MERGE_TW
-#define MS_NTT_MERGE_TW 1
-#endif
-#ifndef MS_NTT_VLOAD_UNROLL
-#define MS_NTT_VLOAD_UNROLL 4   // coefficient + twiddle gathers in flight per thread in the load of the pass behind the virtual pass
-#endif
-  static constexpr bool PREFETCH = MS_NTT_PREFETCH != 0;
-  // Fused tail (r02): the last sub-round's lanes take TWO neighbouring columns of their 2^BL rows, so that what they hold after the
+  // ---- cooperative, persistent form: a workgroup walks tiles g = bx, bx + nbx, ... of the nbatch * tiles of the launch.
+  // Fused tail: the last sub-round's lanes take VEC neighbouring columns of their 2^BL rows, so that what they hold after the
   // butterflies is exactly the 16-byte pieces of the store - no write-back of the last sub-round, no read-back for the store, one
-  // barrier less per tile (measured, 6-column launches: first pass 327.5 -> 313.2 us, later pass 266.6 -> 258.0 us).
-  // MS_NTT_DMA=1 (off): later passes fetch the NEXT tile by LDS-DMA (global_load_lds_dwordx4, no registers) as soon as the last sub-round
-  // has its inputs in registers, so that the loads are in flight during its arithmetic and the store, and wait for them with a counted
-  // vmcnt that leaves the tile's own stores in flight.  Bit-exact (CPU emulation and GPU suite), but no faster: 265 us against 258 -
-  // like a column resident in the Infinity Cache (MS_NTT_COLBATCH), hiding the memory side changes nothing, because these passes are
-  // bound by the CU's instruction issue: per 1536 executed VALU instructions a thread issues ~1180 scalar ones for the exec-masked
-  // corrections plus 670 s_nop wait states (disassembly of the later pass), and a second workgroup per CU buys 1.37x, not 2x.
-#ifndef MS_NTT_FUSE_TAIL
-#define MS_NTT_FUSE_TAIL 1
-#endif
-#ifndef MS_NTT_DMA
-#define MS_NTT_DMA 0
-#endif
-#ifndef MS_NTT_DMA_COUNTED
-#define MS_NTT_DMA_COUNTED 1
-#endif
+  // barrier less per tile.
   static constexpr int TAIL_ITEMS = (R >> BL) * LPR, NJT = (TAIL_ITEMS + TH - 1) / TH;
-  static constexpr bool FUSE_TAIL = MS_NTT_FUSE_TAIL != 0 && MODE != 0 && NSUB == 3 && TAIL_ITEMS % TH == 0 && !PREFETCH;
-  // Fused head (behind the virtual pass): the lane that expands coefficient row (tid >> LC) + j * 2^SLO(0) into column tid & (C - 1) is the lane
-  // whose first sub-round takes exactly these 2^B0 elements - they stay in registers, the tile is first written by the first sub-round
-  // (one LDS round trip less per element; the barrier stays: the boundary table and the reuse of the staging region need it).
-  // OFF: the 2^B0 elements held across that barrier and the table builds push the 2^10-row instance to 128 VGPRs + 10 spilled (44 bytes
-  // of scratch) and the LDE 6 x 2^20 -> 2^23 from 0.583 to 0.593 ms (two interleaved pairs of runs); bit-exact on the emulator.
-#ifndef MS_NTT_FUSE_HEAD
-#define MS_NTT_FUSE_HEAD 0
-#endif
-  static constexpr bool FUSE_HEAD = MS_NTT_FUSE_HEAD != 0 && MODE == 2 && !PREFETCH && MS_NTT_STAGE_SRC != 0 && (TH >> LC) == (1 << DG::slo(0)) &&
-                                    ((R >> DG::bits(0)) * C) == TH && (R * C / TH) == (1 << DG::bits(0)) && DG::slo(0) >= BL + 2;
-  static constexpr int DMA_ROWS = 1024 / (C * (int)sizeof(T)), DMA_INST = R / DMA_ROWS / (TH / 64);   // rows per wave instruction (1 KiB), instructions per wave and tile
-  static constexpr bool DMA = MS_NTT_DMA != 0 && FUSE_TAIL && MODE == 1 && (C * (int)sizeof(T)) == 64 && R % (DMA_ROWS * (TH / 64)) == 0;
-  // LDS slot s of the swizzled tile holds row s ^ ((s >> BL) & 3) (prow is an involution): the swizzle goes on the SOURCE address, the wave's
-  // 64 lanes write 16 consecutive 64-byte slots
-  static MS_DEV void dma_issue(const Params& p, size_t tile_, size_t by_, int tid, T* tile) {
-    const size_t cs = ((size_t)1 << p.log_n) >> K;
-    const T* src = p.src + by_ * p.src_bstride + (tile_ << LC);
-    const int wave = tid >> 6, lane = tid & 63, q = lane % LPR;
-#pragma unroll
-    for (int i = 0; i < DMA_INST; i++) {
-      const int slot0 = (wave * DMA_INST + i) * DMA_ROWS, sl = slot0 + lane / LPR, row = sl ^ ((sl >> BL) & 3);
-      msrt::glds16(src + q * VEC + (size_t)row * cs, tile + (size_t)slot0 * C, lane);
-    }
-  }
-  static constexpr int NROWS = (MODE == 2) ? 1 : SWEEPS, NXS = (MODE == 2) ? (R * C / TH) : 1;   // prefetch registers: whole 16-byte row pieces or, behind the virtual pass, single coefficients
+  static constexpr bool FUSE_TAIL = MODE != 0 && NSUB == 3 && TAIL_ITEMS % TH == 0;
+  // Behind the virtual pass: the tile's R coefficients (one gather each) are fetched ONE TILE AHEAD into NS registers per thread and handed to
+  // the expanding lanes through LDS (the row-twiddle region, free at that point): R gathers per tile instead of R * C broadcast loads.
+  static constexpr bool STAGE = MODE == 2;
+  // ... and an element meets five twiddles there: the virtual pass's at the load, two sub-round boundaries, and at the store w_n^(8 k2 i_new)
+  // (row) and w_n^(k2 i1) (column).  i_new = E0 + 2^B0 E1 + 2^(B0+B1) E2 (one output digit per sub-round), so the row twiddle is a product of
+  // one factor per digit: the factors of E0 and E1 ride on the boundary tables (per tile: tb0[E0][lo] in the w region, tb1[E1][lo] in the
+  // row-twiddle region) and the factor of the last digit is merged with the column twiddle into ts[E_last][i1] - FOUR multiplications per
+  // element instead of five.  All factors are exact field elements, so the regrouping does not change a bit of the result.
+  // Goldilocks only: BabyBear's butterflies read w_r inside the sub-rounds, so its w region cannot be given away.
+  static constexpr bool MERGE = MODE == 2 && F::ID == 0;
+  static constexpr int VLOAD_UNROLL = 4;   // twiddle gathers in flight per thread in the expansion behind the virtual pass
   static MS_DEV void locate(size_t g, size_t tiles, size_t* tile, size_t* by) { *by = g / tiles; *tile = g - *by * tiles; }
-  // issues the global loads of one work item into the caller's registers (fully unrolled: `rows` / `xs` never leave the register file)
-  static MS_DEV void prefetch(const Params& p, size_t tile, size_t by, int tid, V16 (&rows)[NROWS], T (&xs)[NXS]) {
+  // MODE 0 / 1: the tile's rows, SWEEPS 16-byte pieces per lane (fully unrolled: `rows` never leaves the register file)
+  static MS_DEV void load_rows(const Params& p, size_t tile, size_t by, int tid, V16 (&rows)[SWEEPS]) {
     const size_t n = (size_t)1 << p.log_n, cs = n >> K, f0 = tile << LC;
-    const T* src = p.src + by * p.src_bstride;
-    if constexpr (MODE != 2) {
-      const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
-      const T* s0 = src + f0 + c0 + (size_t)rb * cs;
-      if (MODE == 1 || p.n_in >= n) {
+    const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
+    const T* s0 = p.src + by * p.src_bstride + f0 + c0 + (size_t)rb * cs;
+    if (MODE == 1 || p.n_in >= n) {
 #pragma unroll
-#ifdef MS_ABL_NOMEM
-        for (int i = 0; i < SWEEPS; i++) { V16 z; for (int v = 0; v < VEC; v++) z[v] = (T)(tid + i + v); rows[i] = z; }
-#else
-        for (int i = 0; i < SWEEPS; i++) rows[i] = *reinterpret_cast<const V16*>(s0 + (size_t)(i * RPS) * cs);
-#endif
-#ifdef MS_ABL_CONTIGREAD   // ablation (timing only, wrong values): the tile read as ONE contiguous 64 KiB block instead of 1024 pieces 64 KiB apart
-        if constexpr (MODE == 1) {
-          const T* t0 = src + (f0 << K) + (size_t)(rb * C + c0);
-          for (int i = 0; i < SWEEPS; i++) rows[i] = *reinterpret_cast<const V16*>(t0 + (size_t)(i * RPS) * C);
-        }
-#endif
-      } else {
-#pragma unroll
-        for (int i = 0; i < SWEEPS; i++) {
-          const size_t a = f0 + c0 + (size_t)(rb + i * RPS) * cs;
-#pragma unroll
-          for (int v = 0; v < VEC; v++) rows[i][v] = (a + v < p.n_in) ? s0[(size_t)(i * RPS) * cs + v] : (T)0;
-        }
-      }
+      for (int i = 0; i < SWEEPS; i++) rows[i] = *reinterpret_cast<const V16*>(s0 + (size_t)(i * RPS) * cs);
     } else {
-      const size_t k2 = f0 >> LC, nprime = n >> (LC + K);
 #pragma unroll
-      for (int j = 0; j < NXS; j++) {
-        const int row = (tid + j * TH) >> LC;
-        const size_t k = k2 + nprime * (size_t)row;
-        xs[j] = (k < p.n_in) ? src[k] : (T)0;
+      for (int i = 0; i < SWEEPS; i++) {
+        const size_t a = f0 + c0 + (size_t)(rb + i * RPS) * cs;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) rows[i][v] = (a + v < p.n_in) ? s0[(size_t)(i * RPS) * cs + v] : (T)0;
       }
     }
   }
   static MS_DEV void run(const Params& p, int bx, int, int nbx, int tid, unsigned char* lds) {
     T* tile = reinterpret_cast<T*>(lds);
-    T* w = tile + (size_t)R * C;                 // [R]: w_r (sub-round twiddles), loaded once per workgroup
-    T* twr = w + R;                              // [R]: store twiddle of every tile row
+    T* w = tile + (size_t)R * C;                 // [R]: w_r (sub-round twiddles), loaded once per workgroup (MERGE: boundary table tb0, per tile)
+    T* twr = w + R;                              // [R]: store twiddle of every tile row (MODE 2: staged coefficients, then tb1 | ts or the row twiddles)
     const size_t tiles = ((size_t)1 << (p.log_n - K)) >> LC, total = tiles * (size_t)p.nbatch;
     const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
     const bool do_scale = p.do_scale != 0;
     // work items of this workgroup: g(i) for i = 0, 1, ..; XCD x = bx & 7 walks the contiguous range [x * total / 8, (x + 1) * total / 8):
     // behind the virtual pass its workgroups share 64-byte source lines through that XCD's L2; in a later pass the 64 tiles an XCD works on
-    // at a time are 4 KiB runs of every row (measured: 264 -> 257 us per 6-column launch)
-    const bool xcd_map = (MODE == 2 || (MS_NTT_XCD_LATER && MODE == 1)) && (nbx & 7) == 0 && (total & 7) == 0 && total >= 64;
+    // at a time are 4 KiB runs of every row
+    const bool xcd_map = MODE != 0 && (nbx & 7) == 0 && (total & 7) == 0 && total >= 64;
     const size_t stride = xcd_map ? (size_t)(nbx >> 3) : (size_t)nbx, first = xcd_map ? (size_t)(bx >> 3) : (size_t)bx;
     const size_t lim = xcd_map ? (total >> 3) : total, base_g = xcd_map ? (size_t)(bx & 7) * (total >> 3) : 0;
     if (first >= lim) return;
-    // Behind the virtual pass an element meets five twiddles: the virtual pass's at the load, two sub-round boundaries, and at the store
-    // w_n^(8 k2 i_new) (row) and w_n^(k2 i1) (column).  i_new = E0 + 2^B0 E1 + 2^(B0+B1) E2 (one output digit per sub-round), so the row
-    // twiddle is a product of one factor per digit: the factors of E0 and E1 ride on the boundary tables (per tile: tb0[E0][lo] in the w
-    // region, tb1[E1][lo] in the row-twiddle region) and the factor of the last digit is merged with the column twiddle into ts[E_last][i1]
-    // - FOUR multiplications per element instead of five (154 -> 137 VALU instructions per element).  All factors are exact field elements,
-    // so the regrouping does not change a bit of the result.
-    constexpr bool MERGE = MODE == 2 && !PREFETCH && MS_NTT_MERGE_TW && F::ID == 0;   // Goldilocks only: BabyBear's butterflies read w_r inside the sub-rounds, so its w region cannot be given away
     [[maybe_unused]] constexpr int B0 = DG::bits(0), Q0 = 1 << DG::slo(0), Q1 = 1 << DG::slo(1);
     constexpr int NTB1 = NSUB == 3 ? (R >> B0) : 0;          // entries of tb1 (none with two sub-rounds: the second one is the last)
     static_assert(!MERGE || NTB1 + (1 << BL) * C <= R, "merged tables must fit the row-twiddle region");
     [[maybe_unused]] T* tb1 = twr; [[maybe_unused]] T* ts = twr + NTB1;
     if (!MERGE) for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
-    V16 rows[NROWS]; T xs[NXS];
     size_t tl, by;
     locate(base_g + first, tiles, &tl, &by);
-    if (PREFETCH) prefetch(p, tl, by, tid, rows, xs);
-    // behind the virtual pass the tile's R coefficients (one 8-byte gather each) are fetched ONE TILE AHEAD into NS registers per thread and
-    // handed to the expanding lanes through LDS (the row-twiddle region, free at that point): R gathers per tile instead of R * C broadcast loads
-    constexpr bool STAGE = MODE == 2 && !PREFETCH && MS_NTT_STAGE_SRC;
     constexpr int NS = STAGE ? (R + TH - 1) / TH : 1;
-    T sv[NS];
-    [[maybe_unused]] T xh[FUSE_HEAD ? (1 << DG::bits(0)) : 1];   // FUSE_HEAD: the first sub-round's inputs
+    [[maybe_unused]] T sv[NS];
     auto stage_issue = [&](size_t tile_, size_t by_) {
       const size_t nprime = ((size_t)1 << p.log_n) >> (LC + K);
       const T* src = p.src + by_ * p.src_bstride;
@@ -701,96 +607,45 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         sv[j] = (row < R && k < p.n_in) ? src[k] : (T)0;
       }
     };
-    if (STAGE) stage_issue(tl, by);
-    if constexpr (DMA) dma_issue(p, tl, by, tid, tile);
+    if constexpr (STAGE) stage_issue(tl, by);
     for (size_t it = first; it < lim; it += stride) {
       locate(base_g + it, tiles, &tl, &by);
-      if (!PREFETCH && MODE != 2 && !DMA) prefetch(p, tl, by, tid, rows, xs);
       const size_t f0 = tl << LC;
       const bool row_tw = MODE != 0 && !p.last && (f0 >> p.log_Rp) != 0;
-      // ---- the prefetched inputs go to LDS (behind the virtual pass: times w_(r0 r)^(i1 * row)); the row twiddles of this tile
-#ifdef MS_ABL_COPYONLY   // ablation: the pass's global access pattern alone (rows in, rows out), no LDS, no barriers, no arithmetic
-      if constexpr (MODE == 1) {
-        const size_t k_low_ = f0 >> p.log_Rp, i_done_ = (f0 & (((size_t)1 << p.log_Rp) - 1)) + c0;
-        T* out_ = p.dst + by * p.dst_bstride + ((k_low_ << p.log_Rp) << K) + i_done_;
-#pragma unroll
-#ifdef MS_ABL_CONTIGWRITE
-        for (int i = 0; i < SWEEPS; i++) *reinterpret_cast<V16*>(p.dst + by * p.dst_bstride + (f0 << K) + (size_t)(rb * C + c0) + (size_t)(i * RPS) * C) = rows[i];
-#else
-        for (int i = 0; i < SWEEPS; i++) *reinterpret_cast<V16*>(out_ + ((size_t)row_to_inew(rb + i * RPS) << p.log_Rp)) = rows[i];
-#endif
-        continue;
-      }
-#endif
-      if (row_tw && !STAGE) {
-        const size_t k_low = f0 >> p.log_Rp;
-        for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);   // w_n^(k_low * Rp * i_new)
-      }
-      if constexpr (DMA) {}   // the tile was fetched by LDS-DMA (issued in the previous tile's tail, or before the loop)
-      else if constexpr (MODE != 2) {
+      // ---- load: the tile's inputs go to LDS (behind the virtual pass: times w_(r0 r)^(i1 * row)); the row twiddles of this tile
+      if constexpr (MODE != 2) {
+        V16 rows[SWEEPS];
+        load_rows(p, tl, by, tid, rows);
+        if (row_tw) {
+          const size_t k_low = f0 >> p.log_Rp;
+          for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);   // w_n^(k_low * Rp * i_new)
+        }
 #pragma unroll
         for (int i = 0; i < SWEEPS; i++) *reinterpret_cast<V16*>(tile + tix(rb + i * RPS, c0)) = rows[i];
       } else {
         // virtual r0-point pass (r0 = C, only the first n/r0 inputs non-zero): A_1[k2*r0 + i1] = w_n^(i1*k) x[k], k = k2 + nprime*row.
         // The k2 part of the twiddle rides on the store twiddle; here x[k] * w_(r0 r)^(i1 * row).  One lane per tile element.
-        if (PREFETCH) {
 #pragma unroll
-          for (int j = 0; j < NXS; j++) {
-            const int idx = tid + j * TH, row = idx >> LC, i1 = idx & (C - 1);
-            T v = xs[j];
-            if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
-            tile[tix(row, i1)] = v;
-          }
-        } else {
-          const size_t n = (size_t)1 << p.log_n, k2 = f0 >> LC, nprime = n >> (LC + K);
-          const T* src = p.src + by * p.src_bstride;
-          if constexpr (STAGE) {
-#pragma unroll
-            for (int j = 0; j < NS; j++) { const int row = tid + j * TH; if (row < R) twr[row] = sv[j]; }
-            msrt::wg_barrier();
-          }
-          if constexpr (MERGE) {   // tb0[E0][lo] = w_r^(E0 lo) * w_n^(X E0), X = k_low * Rp (the previous tile's last reader is behind the end-of-tile barrier)
-            const size_t X = (f0 >> p.log_Rp) << p.log_Rp;
-            for (int idx = tid; idx < R; idx += TH) {
-              const int e = idx >> DG::slo(0), lo = idx & (Q0 - 1);
-              T v = p.w_r[e * lo];
-              if (X && e) v = A::mul_tw(v, tw_global(p, X * (size_t)e));
-              w[idx] = v;
-            }
-          }
-          if constexpr (FUSE_HEAD) {
-            const int i1 = tid & (C - 1), row0 = tid >> LC;
-#pragma unroll
-            for (int j = 0; j < (1 << DG::bits(0)); j++) {
-              const int row = row0 + (j << DG::slo(0));
-              T v = twr[row];
-              if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
-              xh[j] = v;
-            }
-          } else
-#pragma unroll MS_NTT_VLOAD_UNROLL
-          for (int idx = tid; idx < R * C; idx += TH) {
-            const int row = idx >> LC, i1 = idx & (C - 1);
-            const size_t k = k2 + nprime * (size_t)row;
-#ifdef MS_ABL_A_NOSRC
-            T v = (T)(k + 1);
-#else
-            T v = STAGE ? twr[row] : ((k < p.n_in) ? src[k] : (T)0);
-#endif
-#ifdef MS_ABL_A_NOVTW
-            if (i1) v = A::mul_tw(v, p.scale);
-#else
-            if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
-#endif
-            tile[tix(row, i1)] = v;
+        for (int j = 0; j < NS; j++) { const int row = tid + j * TH; if (row < R) twr[row] = sv[j]; }
+        msrt::wg_barrier();
+        if constexpr (MERGE) {   // tb0[E0][lo] = w_r^(E0 lo) * w_n^(X E0), X = k_low * Rp (the previous tile's last reader is behind the end-of-tile barrier)
+          const size_t X = (f0 >> p.log_Rp) << p.log_Rp;
+          for (int idx = tid; idx < R; idx += TH) {
+            const int e = idx >> DG::slo(0), lo = idx & (Q0 - 1);
+            T v = p.w_r[e * lo];
+            if (X && e) v = A::mul_tw(v, tw_global(p, X * (size_t)e));
+            w[idx] = v;
           }
         }
+#pragma unroll VLOAD_UNROLL
+        for (int idx = tid; idx < R * C; idx += TH) {
+          const int row = idx >> LC, i1 = idx & (C - 1);
+          T v = twr[row];
+          if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
+          tile[tix(row, i1)] = v;
+        }
       }
-      if constexpr (DMA) {
-        // this tile's copies were issued before the previous tile's NJT << BL store instructions (nothing else touches vector memory in between
-        // when the pass has no row twiddles): wait for the copies, not for the acknowledgement of those stores
-        if (MS_NTT_DMA_COUNTED && p.last && it != first) msrt::wg_barrier_vm_but<(NJT << BL)>(); else msrt::wg_barrier_vm();
-      } else msrt::wg_barrier();
+      msrt::wg_barrier();
       if constexpr (MERGE) {   // the staged coefficients have been consumed: the region takes tb1 (read after the next barrier) and ts (read in the store phase)
         const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
         for (int idx = tid; idx < NTB1 + (1 << BL) * C; idx += TH) {
@@ -807,31 +662,26 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
             ts[j] = v;
           }
         }
-      } else if (row_tw && STAGE) {   // the staged coefficients have been consumed: the region takes the row twiddles (read in the store phase)
-        const size_t k_low = f0 >> p.log_Rp;
-        for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);
+      } else if constexpr (STAGE) {   // the staged coefficients have been consumed: the region takes the row twiddles (read in the store phase)
+        if (row_tw) {
+          const size_t k_low = f0 >> p.log_Rp;
+          for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);
+        }
       }
-      if (STAGE && it + stride < lim) {   // next tile's coefficients: in flight during the sub-rounds and the store
-        size_t ntl, nby;
-        locate(base_g + it + stride, tiles, &ntl, &nby);
-        stage_issue(ntl, nby);
+      if constexpr (STAGE) {
+        if (it + stride < lim) {   // next tile's coefficients: in flight during the sub-rounds and the store
+          size_t ntl, nby;
+          locate(base_g + it + stride, tiles, &ntl, &nby);
+          stage_issue(ntl, nby);
+        }
       }
-#ifndef MS_ABL_NOCOMPUTE   // ablation builds (tools/ntt_ablate.sh): memory-only / compute-only timings of the same kernel
-      if constexpr (FUSE_HEAD) sub0_regs<MERGE>(xh, tid, tile, w); else sub_items<0, 0, MERGE>(tid, tile, w);
-#endif
+      sub_items<0, 0, MERGE>(tid, tile, w);
       msrt::wg_barrier();
-      if (PREFETCH && it + stride < lim) {   // next tile's loads: in flight during the remaining sub-rounds and the store
-        size_t ntl, nby;
-        locate(base_g + it + stride, tiles, &ntl, &nby);
-        prefetch(p, ntl, nby, tid, rows, xs);
-      }
-#ifndef MS_ABL_NOCOMPUTE
       if constexpr (MERGE && NSUB == 3) sub_items<1, 0, true>(tid, tile, tb1); else sub_items<1, 0>(tid, tile, w);
-#endif
       msrt::wg_barrier();
       T* dst = p.dst + by * p.dst_bstride;
       if constexpr (FUSE_TAIL) {
-        // ---- last sub-round + store, fused: item = (row group g of 2^BL rows, column pair cp); the rows of a group are the last digit
+        // ---- last sub-round + store, fused: item = (row group g of 2^BL rows, column piece cq); the rows of a group are the last digit
         // E2 = 0 .. 2^BL - 1 of the output index, i_new = E0 + 2^B0 E1 + 2^(B0+B1) E2 with (E0, E1) = the digits of g
         constexpr int NE = 1 << BL, B0_ = DG::bits(0), B1_ = DG::bits(1);
         const size_t k_low = f0 >> p.log_Rp;
@@ -843,10 +693,6 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
           const int itq = tid + J * TH, cq = (itq % LPR) * VEC, g = itq / LPR, R0 = g << BL, h3 = g & 3;
 #pragma unroll
           for (int e = 0; e < NE; e++) o[J][e] = *reinterpret_cast<const V16*>(tile + (size_t)(R0 + (e & ~3) + ((e & 3) ^ h3)) * C + cq);
-        }
-        if constexpr (DMA) {
-          msrt::wg_barrier();                        // every lane has its inputs: the tile buffer is free
-          if (it + stride < lim) { size_t ntl, nby; locate(base_g + it + stride, tiles, &ntl, &nby); dma_issue(p, ntl, nby, tid, tile); }
         }
 #pragma unroll
         for (int J = 0; J < NJT; J++) {
@@ -860,9 +706,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
             T x[NE];
 #pragma unroll
             for (int e = 0; e < NE; e++) x[e] = o[J][e][v];
-#ifndef MS_ABL_NOCOMPUTE
             dif_regs<A, INV, BL>(x, w, K);
-#endif
 #pragma unroll
             for (int e = 0; e < NE; e++) {
               T y = x[bitrev(e, BL)];
@@ -876,12 +720,10 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #pragma unroll
           for (int e = 0; e < NE; e++) *reinterpret_cast<V16*>(outb + cq + ((size_t)(inew0 | (e << (B0_ + B1_))) << p.log_Rp)) = o[J][e];
         }
-        if (!DMA || !p.last) msrt::wg_barrier();     // the tile (no DMA) and the per-tile tables are free for the next work item
+        msrt::wg_barrier();     // the tile and the per-tile tables are free for the next work item
         continue;
       }
-#ifndef MS_ABL_NOCOMPUTE
       if constexpr (NSUB >= 3) { sub_items<2, 0>(tid, tile, w); msrt::wg_barrier(); }
-#endif
       // ---- store
       if constexpr (MODE != 0) {
         // out = k_low*Rp*r + i_done + Rp*i_new: a tile row is one 16*LPR-byte run
@@ -906,11 +748,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
             if (do_scale) x = A::mul_tw(x, p.scale);
             o[v] = x;
           }
-#ifdef MS_ABL_NOMEM
-          if (o[0] == 0x1234567 && tid == 777) *reinterpret_cast<V16*>(out + ((size_t)inew << p.log_Rp)) = o;   // keeps the computation alive, stores (almost) nothing
-#else
           *reinterpret_cast<V16*>(out + ((size_t)inew << p.log_Rp)) = o;
-#endif
         }
       } else {
         // first pass of a plain transform: out = f*r + i_new, i_new fastest across lanes
@@ -933,6 +771,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     }
   }
 };
+
 
 // LAST pass of a small radix (2^K <= 32 points), whole DFT in registers: the rows of this pass are contiguous runs of n / 2^K elements,
 // so a lane takes VEC neighbouring columns, loads their 2^K row elements (16-byte loads, fully coalesced), transforms, stores.  No LDS, no

@@ -14,6 +14,7 @@
 // = elements read + written once.
 #pragma once
 #include "field.hpp"
+#include "ntt.hpp"
 
 namespace mspoly {
 
@@ -589,4 +590,32 @@ template <class F, int E> struct QueryPointsKernel {
   }
 };
 
+
+// ms_arith_selftest: one operation of the NTT tiles' arithmetic class per element (A = GLM for Goldilocks: inline asm with hand-managed
+// gfx950 wait states, which only a run on the device can check; BB for BabyBear).  Ops: include/ministark.h.
+template <int S> struct ArithShift { template <class A> static MS_DEV u64 run(u64 x, int s) { return s == S ? msntt::gl_mul_pow2<S, A>(x) : ArithShift<S - 1>::template run<A>(x, s); } };
+template <> struct ArithShift<0> { template <class A> static MS_DEV u64 run(u64 x, int) { return x; } };
+template <class F, class A> struct ArithKernel {
+  typedef typename F::T T;
+  static constexpr int THREADS = 256;
+  struct Params { const u64* a; const u64* b; u64* out; size_t n; int op; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int, unsigned char*) {
+    const size_t i = (size_t)bx * THREADS + tid;
+    if (i >= p.n) return;
+    const T a = F::from_u64(p.a[i]), b = F::from_u64(p.b[i]);
+    T r = 0;
+    if (p.op == 0) r = A::add(a, b);
+    else if (p.op == 1) r = A::sub(a, b);
+    else if (p.op == 2) r = A::mul(a, b);
+    else if (p.op == 3) r = A::mul_tw(a, F::to_tw(b));
+    if constexpr (F::ID == 0) {
+      if (p.op == 4) r = A::mul_x32(a);
+      else if (p.op == 5) r = A::mul_x64(a);
+      else if (p.op == 6) r = ArithShift<95>::template run<A>(a, (int)(p.b[i] % 96));
+      else if (p.op == 7) r = A::fold_small(a, (u32)p.b[i] & 0x7FFFFFFFu);
+    }
+    p.out[i] = F::to_u64(r);
+  }
+};
 }  // namespace mspoly

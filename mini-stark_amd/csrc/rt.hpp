@@ -102,12 +102,6 @@ struct FiberBlock {
   }
 };
 inline void wg_barrier() { FiberBlock::active()->yield(); }
-// wg_barrier that also retires the caller's outstanding global -> LDS copies (glds16): in the emulation they are done at issue
-inline void wg_barrier_vm() { FiberBlock::active()->yield(); }
-template <int N> inline void wg_barrier_vm_but() { FiberBlock::active()->yield(); }
-// asynchronous 16-byte global -> LDS copy of one lane: the wave's 64 lanes fill 1 KiB at `lds_wave_base` in lane order (LDS-DMA: the
-// destination is wave-uniform base + lane * 16, only the SOURCE is per lane); visible after wg_barrier_vm()
-inline void glds16(const void* gsrc, void* lds_wave_base, int lane) { std::memcpy((unsigned char*)lds_wave_base + lane * 16, gsrc, 16); }
 // value of lane (lane ^ mask) of the caller's 64-lane wave; every thread of the workgroup must call it (like __shfl_xor under full exec)
 inline unsigned long long wave_shfl_xor(unsigned long long v, int mask) {
   FiberBlock* b = FiberBlock::active(); const int t = b->cur;
@@ -251,21 +245,8 @@ inline int launch_coop(Stream* s, unsigned gx, unsigned gy, int threads, size_t 
 // Workgroup barrier of the cooperative kernels, ordering LDS traffic only: __syncthreads() also drains the vector-memory counter
 // (s_waitcnt vmcnt(0)), which would end every prefetch (global loads issued for the NEXT tile) at the first barrier behind it.
 // Global data written before the barrier is NOT made visible by it (these kernels never hand global data between waves).
-#ifdef MS_ABL_NOBARRIER   // ablation (timing only, wrong results): what the workgroup barriers cost
-MS_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
+
 MS_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
-// the same, but the wave first waits for its vector-memory counter: its global_load_lds copies (glds16) have landed in LDS
-MS_DEV void wg_barrier_vm() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// ... all but its N youngest vector-memory operations: the counter retires in issue order, so the copies issued BEFORE the wave's last N
-// global stores have landed while those stores may still be on their way (no wait for their acknowledgement)
-template <int N> MS_DEV void wg_barrier_vm_but() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory"); }
-// asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4, no VGPR destination): the wave's lanes fill 1 KiB at the
-// wave-uniform `lds_wave_base` in lane order, each from its own source address; retired by wg_barrier_vm()
-MS_DEV void glds16(const void* gsrc, void* lds_wave_base, int) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 MS_DEV unsigned long long wave_shfl_xor(unsigned long long v, int mask) { return __shfl_xor(v, mask, 64); }
 MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { atomicMin(a, v); }
 MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { atomicMax(a, v); }

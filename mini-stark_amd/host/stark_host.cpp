@@ -104,6 +104,8 @@ struct PinnedBuf {
   PinnedBuf() {}
   PinnedBuf(const PinnedBuf& o) { assign(o.p, o.p + o.n); }
   PinnedBuf& operator=(const PinnedBuf& o) { if (this != &o) assign(o.p, o.p + o.n); return *this; }
+  PinnedBuf(PinnedBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap), pinned(o.pinned) { o.p = nullptr; o.n = o.cap = 0; }
+  PinnedBuf& operator=(PinnedBuf&& o) noexcept { if (this != &o) { drop(); p = o.p; n = o.n; cap = o.cap; pinned = o.pinned; o.p = nullptr; o.n = o.cap = 0; } return *this; }
   ~PinnedBuf() { drop(); }
   void reserve(size_t m) {
     if (m <= cap) return;
@@ -148,15 +150,19 @@ struct StarkConfig {  // src/starks.rs:238-333
 };
 
 struct Stark {
-  StarkConfig cfg; StarkProof proof;
+  // TWO proof slots: prove() k + 1 fills the slot proof k - 1 lived in, so that proof k - transcript, values, and its page-locked
+  // FRI blob, possibly still arriving on the copy stream - stays whole and readable (`prev`, msh_prev_proof_*) while proof k + 1 is computed.
+  StarkConfig cfg; StarkProof proof, prev;
   // src/starks.rs:59-169
   // read_fri_proof: 0 the FRI proof stays in HBM; 1 read back before returning; 2 read back ASYNCHRONOUSLY (ms_fri_proof_read_async: the bytes
-  // land in the page-locked buffer while the caller goes on - e.g. into the next prove; wait_proof() / any accessor of the blob completes it)
+  // land in the slot's page-locked buffer while the caller goes on - e.g. into the next prove; wait_proof() / any accessor of the blob completes
+  // it); 3 the query-phase kernels write the blob straight INTO the slot's page-locked buffer (ms_fri_query_into: no copy at all)
   int wait_proof() const { return cfg.ctx ? ms_fri_proof_wait(cfg.ctx) : 0; }
   int prove(const TraceTable& trace, int read_fri_proof) {
     const StarkConfig& c = cfg; ms_ctx* ctx = c.ctx; const int e = c.e; const u64 p = c.p;
+    std::swap(proof, prev);   // (PinnedBuf moves by pointer swap below: the buffers stay where the device writes them)
     StarkProof& pr = proof;
-    pr.arthur.clear(); pr.evals.clear(); pr.fri_roots.clear(); pr.challenges.clear(); pr.c = 0; pr.fri_blob.n = 0;   // the page-locked proof buffer is kept across proofs
+    pr.arthur.clear(); pr.evals.clear(); pr.fri_roots.clear(); pr.challenges.clear(); pr.c = 0; pr.fri_blob.n = 0;   // the page-locked proof buffers are kept across proofs
     Transcript t(c.domsep);
     int rc;
     // 1.1 commit to the raw trace (starks.rs:68-73)
@@ -199,10 +205,17 @@ struct Stark {
     std::vector<u8> raw(8 * c.fri_queries); t.challenge_bytes(raw.data(), raw.size());        // fri.rs:121-122
     std::vector<u64> betas(c.fri_queries);
     for (size_t i = 0; i < betas.size(); i++) memcpy(&betas[i], raw.data() + 8 * i, 8);        // usize::from_le_bytes, fri.rs:123-126
-    if ((rc = ms_fri_query(ctx, betas.data(), (int)betas.size()))) return rc;
+    if (read_fri_proof == 3) {
+      size_t need = 0;
+      if ((rc = ms_fri_proof_wait(ctx))) return rc;          // this slot's buffer may still be the target of proof k - 2's asynchronous read-back
+      if ((rc = ms_fri_query_into(ctx, betas.data(), (int)betas.size(), nullptr, 0, &need))) return rc;
+      pr.fri_blob.resize_uninit(need ? need : 1);
+      if ((rc = ms_fri_query_into(ctx, betas.data(), (int)betas.size(), pr.fri_blob.data(), pr.fri_blob.size(), &need))) return rc;
+      pr.fri_blob.n = need;
+    } else if ((rc = ms_fri_query(ctx, betas.data(), (int)betas.size()))) return rc;
     pr.challenges.insert(pr.challenges.end(), betas.begin(), betas.end());
-    if (read_fri_proof) {
-      if ((rc = ms_fri_proof_wait(ctx))) return rc;          // an earlier asynchronous read-back into this buffer (long finished by now)
+    if (read_fri_proof == 1 || read_fri_proof == 2) {
+      if ((rc = ms_fri_proof_wait(ctx))) return rc;          // an earlier asynchronous read-back (proof k - 1's: one copy in flight per context)
       pr.fri_blob.resize_uninit(ms_fri_proof_size(ctx));
       if (!pr.fri_blob.empty() && (rc = (read_fri_proof == 2 ? ms_fri_proof_read_async(ctx, pr.fri_blob.data()) : ms_fri_proof_read(ctx, pr.fri_blob.data())))) return rc;
     }
@@ -404,12 +417,32 @@ int msh_proof_wait(const msh_stark* h) { return h->s.wait_proof(); }
 size_t msh_proof_fri_blob(const msh_stark* h, u8* out, size_t cap) { h->s.wait_proof(); return copy_out(h->s.proof.fri_blob.data(), h->s.proof.fri_blob.size(), out, cap); }
 size_t msh_proof_challenges(const msh_stark* h, u64* out, size_t cap_elems) { return copy_out(h->s.proof.challenges.data(), h->s.proof.challenges.size() * 8, out, cap_elems * 8) / 8; }
 size_t msh_proof_num_polys(const msh_stark* h) { return h->s.proof.c; }
+// the proof BEFORE the last one (the other slot): still whole while / after the next msh_stark_prove runs.  msh_prev_proof_fri_blob waits for an
+// asynchronous read-back in flight on the context (mode 2: at most the copy of the last proof, issued after this one's had finished).
+size_t msh_prev_proof_arthur(const msh_stark* h, u8* out, size_t cap) { return copy_out(h->s.prev.arthur.data(), h->s.prev.arthur.size(), out, cap); }
+size_t msh_prev_proof_fri_roots(const msh_stark* h, u8* out, size_t cap) { return copy_out(h->s.prev.fri_roots.data(), h->s.prev.fri_roots.size(), out, cap); }
+size_t msh_prev_proof_fri_blob(const msh_stark* h, u8* out, size_t cap) { return copy_out(h->s.prev.fri_blob.data(), h->s.prev.fri_blob.size(), out, cap); }
+// FNV-1a over the FRI blob of the last (which = 0) or the previous (which = 1) proof, read IN PLACE from the page-locked slot: what a consumer
+// that streams the proof out would touch (bench.py's I/O-inclusive leg reads every proof this way); 0 if there is none
+u64 msh_proof_blob_checksum(const msh_stark* h, int which) {
+  if (which == 0) h->s.wait_proof();
+  const PinnedBuf& b = which ? h->s.prev.fri_blob : h->s.proof.fri_blob;
+  u64 x = 0xCBF29CE484222325ULL;
+  const u64* w = (const u64*)b.data();
+  for (size_t i = 0; i < b.size() / 8; i++) { x ^= w[i]; x *= 0x100000001B3ULL; }
+  return b.size() ? x : 0;
+}
+static int set_why(char* why, size_t why_cap, const char* msg, int rc);
 // Stark::verify (src/starks.rs:171-235) of a proof given by its parts; `constrains` = the c constraint polynomials in coefficient
 // form ([c][N] canonical u64: what trace.derive_constrains() hands the reference's verifier).  1 accepted, 0 rejected, < 0 malformed;
 // the reason is copied to `why`.
 int msh_stark_verify(const msh_stark* h, const u64* constrains, size_t c, size_t N, const u8* arthur, size_t arthur_len, const u8* trace_commit,
                      const u8* lde_commit, const u64* evals, size_t nevals, const u8* fri_roots, size_t nroots, const u8* blob, size_t blob_len,
                      int zero_display_empty, char* why, size_t why_cap) {
+  if (!h || !constrains || !trace_commit || !lde_commit || (!arthur && arthur_len) || (!evals && nevals) || (!fri_roots && nroots) || (!blob && blob_len) ||
+      arthur_len > ((size_t)1 << 32) || nroots > 64 || nevals > ((size_t)1 << 40) || blob_len > ((size_t)1 << 44))
+    return set_why(why, why_cap, "malformed proof (null part or absurd length)", -1);
+  try {
   StarkProof pr;
   pr.arthur.assign(arthur, arthur + arthur_len);
   memcpy(pr.trace_commit, trace_commit, 32); memcpy(pr.constrain_trace_commit, lde_commit, 32);
@@ -422,6 +455,7 @@ int msh_stark_verify(const msh_stark* h, const u64* constrains, size_t c, size_t
   else rc = Verifier<BB, 4>::run(h->s.cfg, constrains, c, N, pr, zero_display_empty, &reason);
   if (why && why_cap) { size_t n = reason.size() < why_cap - 1 ? reason.size() : why_cap - 1; memcpy(why, reason.data(), n); why[n] = 0; }
   return rc;
+  } catch (...) { return set_why(why, why_cap, "out of memory / internal error while verifying", -1); }   // nothing unwinds through the C boundary
 }
 // ---- whole-proof wire format "MSSP" v1 (layout in include/ministark_host.h) ----------------------------
 static const size_t MSSP_HEAD = 4 + 5 * 4 + 2 * 8;
@@ -444,35 +478,80 @@ size_t msh_proof_serialize(const msh_stark* h, u8* out, size_t cap) {
   put(pr.fri_roots.data(), pr.fri_roots.size()); put(pr.arthur.data(), la); put(pr.fri_blob.data(), lb);
   return need;
 }
-// parses an MSSP blob: 0 on success (fields of `v` point INTO `data`), -1 malformed
+// parses an MSSP blob: 0 on success (fields of `v` point INTO `data`), -1 malformed.  Every length is checked against the bytes that
+// are LEFT, field by field, with comparisons that cannot wrap (a single wrapping sum let arthur_len = 2^64 - 1000 through).
 int msh_proof_parse(const u8* data, size_t len, msh_proof_view* v) {
   if (!data || !v || len < MSSP_HEAD + 64 || memcmp(data, "MSSP", 4) != 0) return -1;
   u32 ver; memcpy(&ver, data + 4, 4); if (ver != 1) return -1;
   memcpy(&v->e, data + 8, 4); memcpy(&v->c, data + 12, 4); memcpy(&v->q, data + 16, 4); memcpy(&v->rounds, data + 20, 4);
   memcpy(&v->arthur_len, data + 24, 8); memcpy(&v->fri_blob_len, data + 32, 8);
-  const size_t ev = (size_t)v->q * (v->c + 1) * v->e * 8;
-  const size_t need = MSSP_HEAD + 64 + ev + (size_t)v->rounds * 32 + v->arthur_len + v->fri_blob_len;
-  if (need != len) return -1;
+  if ((v->e != 2 && v->e != 4) || v->c == 0 || v->c > (1u << 20) || v->q > (1u << 16) || v->rounds == 0 || v->rounds > 64) return -1;
+  size_t left = len - (MSSP_HEAD + 64);
+  const u64 ev = (u64)v->q * ((u64)v->c + 1) * v->e * 8;          // < 2^16 * 2^21 * 4 * 8 = 2^42: no wrap
+  if (ev > left) return -1;
+  left -= (size_t)ev;
+  const size_t rb = (size_t)v->rounds * 32;
+  if (rb > left) return -1;
+  left -= rb;
+  if (v->arthur_len > left) return -1;
+  left -= (size_t)v->arthur_len;
+  if (v->fri_blob_len != left) return -1;                          // the blob is the rest, exactly
   const u8* p = data + MSSP_HEAD;
   v->trace_commit = p; v->constrain_trace_commit = p + 32; p += 64;
   v->constrain_queries = (const u64*)p; p += (size_t)v->q * v->c * v->e * 8;
   v->validity_queries = (const u64*)p; p += (size_t)v->q * v->e * 8;
-  v->fri_roots = p; p += (size_t)v->rounds * 32;
+  v->fri_roots = p; p += rb;
   v->arthur = p; p += v->arthur_len;
   v->fri_blob = p;
   return 0;
 }
+static int set_why(char* why, size_t why_cap, const char* msg, int rc) { if (why && why_cap) { strncpy(why, msg, why_cap - 1); why[why_cap - 1] = 0; } return rc; }
 // Stark::verify straight from the wire format: 1 accepted, 0 rejected, < 0 malformed
 int msh_stark_verify_mssp(const msh_stark* h, const u64* constrains, size_t c, size_t N, const u8* data, size_t len, int zero_display_empty, char* why, size_t why_cap) {
-  msh_proof_view v;
-  if (msh_proof_parse(data, len, &v) || v.c != c || (int)v.e != h->s.cfg.e) { if (why && why_cap) { strncpy(why, "malformed MSSP proof", why_cap - 1); why[why_cap - 1] = 0; } return -1; }
-  std::vector<u64> evals((size_t)v.q * (v.c + 1) * v.e);
-  for (u32 i = 0; i < v.q; i++) {
-    memcpy(evals.data() + (size_t)i * (v.c + 1) * v.e, v.constrain_queries + (size_t)i * v.c * v.e, (size_t)v.c * v.e * 8);
-    memcpy(evals.data() + ((size_t)i * (v.c + 1) + v.c) * v.e, v.validity_queries + (size_t)i * v.e, (size_t)v.e * 8);
-  }
-  return msh_stark_verify(h, constrains, c, N, v.arthur, v.arthur_len, v.trace_commit, v.constrain_trace_commit, evals.data(), evals.size(), v.fri_roots, v.rounds,
-                          v.fri_blob, v.fri_blob_len, zero_display_empty, why, why_cap);
+  if (!h || !constrains) return set_why(why, why_cap, "null argument", -1);
+  try {
+    msh_proof_view v;
+    if (msh_proof_parse(data, len, &v) || v.c != c || (int)v.e != h->s.cfg.e) return set_why(why, why_cap, "malformed MSSP proof", -1);
+    // the sizes that feed allocations come from the HANDLE's configuration, never from the wire
+    if (v.q != h->s.cfg.constrain_queries || v.rounds != h->s.cfg.rounds) return set_why(why, why_cap, "MSSP proof does not match this configuration (queries / rounds)", -1);
+    std::vector<u64> evals((size_t)v.q * (v.c + 1) * v.e);
+    for (u32 i = 0; i < v.q; i++) {
+      memcpy(evals.data() + (size_t)i * (v.c + 1) * v.e, v.constrain_queries + (size_t)i * v.c * v.e, (size_t)v.c * v.e * 8);
+      memcpy(evals.data() + ((size_t)i * (v.c + 1) + v.c) * v.e, v.validity_queries + (size_t)i * v.e, (size_t)v.e * 8);
+    }
+    return msh_stark_verify(h, constrains, c, N, v.arthur, v.arthur_len, v.trace_commit, v.constrain_trace_commit, evals.data(), evals.size(), v.fri_roots, v.rounds,
+                            v.fri_blob, v.fri_blob_len, zero_display_empty, why, why_cap);
+  } catch (...) { return set_why(why, why_cap, "out of memory / internal error while verifying", -1); }
+}
+// FriProof (src/fri.rs:17-22) out of its MSFP bytes (layout: ministark.h) - the compiled counterpart of the Rust shim's FriProof::from_msfp
+// (examples/rust_shim/src/fri_proof.rs): `windows` = rounds - 1, `nq` queries per window, E limbs per element.  Fills up to `cap` records
+// (views INTO `blob`), returns the number of records (windows * nq) or -1 if the bytes do not parse exactly.
+int msh_fri_proof_parse(const u8* blob, size_t len, u32 e, u32 windows, u32 nq, msh_fri_query_view* out, size_t cap) {
+  if ((!blob && len) || (e != 1 && e != 2 && e != 4) || windows > 64 || nq > (1u << 16)) return -1;
+  const u8* p = blob; size_t left = len; size_t n = 0;
+  auto path = [&](msh_merkle_path_view* mp) -> bool {
+    const size_t head = 8 + (size_t)2 * e * 8 + 8;                   // leaf_index | lpn = 2 leaf_neighbours | nlevels
+    if (left < head) return false;
+    u64 nlev; memcpy(&mp->leaf_index, p, 8); memcpy(&nlev, p + 8 + (size_t)2 * e * 8, 8);
+    if (nlev > 64 || left - head < (size_t)nlev * 64) return false;
+    mp->leaf_neighbours = (const u64*)(p + 8); mp->nlevels = nlev; mp->levels = p + head;
+    p += head + (size_t)nlev * 64; left -= head + (size_t)nlev * 64;
+    return true;
+  };
+  for (u32 i = 0; i < windows; i++)
+    for (u32 j = 0; j < nq; j++, n++) {
+      msh_fri_query_view q;
+      const size_t head = ((size_t)6 * e + 1) * 8;
+      if (left < head) return -1;
+      q.points = (const u64*)p;
+      memcpy(&q.qlen, p + (size_t)6 * e * 8, 8);
+      if (q.qlen > ((u64)1 << 40) || left - head < (size_t)q.qlen * e * 8) return -1;
+      q.quotient = (const u64*)(p + head);
+      p += head + (size_t)q.qlen * e * 8; left -= head + (size_t)q.qlen * e * 8;
+      if (!path(&q.path[0]) || !path(&q.path[1])) return -1;
+      if (out && n < cap) out[n] = q;
+    }
+  return left == 0 ? (int)n : -1;
 }
 // the synthetic Fibonacci-AIR trace of the benchmark workload (tests/e2e_goldilocks.rs:20-63 rows + SplitMix64 padding; = mini_stark_amd.synthetic.fibonacci_rows)
 int msh_fibonacci_rows(u64 p, size_t length, size_t steps, u64 secret_b, u64 pad_seed, u64* out) {

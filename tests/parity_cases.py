@@ -384,3 +384,39 @@ def case_device_trace_range_check(mk, field, to_device):
     assert ctx.trace_commit_device(ptr, 16, 3, 6)[0] == ms.ERR_ARG
     assert ctx.interpolate() == ms.ERR_STATE      # the failed commit left no trace behind
     del keep, keep2
+
+
+def case_arith_selftest(mk, field, nrand=1 << 16):
+    """ms_arith_selftest: every operation of the NTT tiles' arithmetic class (Goldilocks on the GPU: GLM, exec-masked inline asm with
+    hand-managed wait states - ADVICE r2: the one class no CPU build can execute) against Python big integers, on all pairs of directed
+    edge values (operands that force a carry, a borrow, both, or neither; values around p, 2^32 and 2^63) and on random pairs."""
+    p = MODULUS[field]
+    if field == 0:
+        edge = [0, 1, 2, p - 1, p - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 0xFFFFFFFEFFFFFFFF, 1 << 63, (1 << 63) - 1, 0xFFFFFFFE, 0x1FFFFFFFF,
+                0xFFFFFFFE00000001, 0xFFFFFFFE00000002, 0x7FFFFFFF80000001, 0x80000000FFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF00000000 - 1]
+    else:
+        edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 30, (1 << 30) - 1, 0x77FFFFFF, 0x78000000, 0x78000001 % p, 1172168163]
+    edge = [v % p for v in edge]
+    a = [x for x in edge for _ in edge]
+    b = [y for _ in edge for y in edge]
+    rng = np.random.RandomState(12345)
+    ra = [int(v) % p for v in (rng.randint(0, 1 << 62, size=nrand, dtype=np.int64).astype(np.uint64) * np.uint64(4) + rng.randint(0, 4, size=nrand).astype(np.uint64))]
+    rb = [int(v) % p for v in (rng.randint(0, 1 << 62, size=nrand, dtype=np.int64).astype(np.uint64) * np.uint64(4) + rng.randint(0, 4, size=nrand).astype(np.uint64))]
+    a, b = a + ra, b + rb
+    ctx = mk(field)
+    ops = {0: lambda x, y: (x + y) % p, 1: lambda x, y: (x - y) % p, 2: lambda x, y: x * y % p, 3: lambda x, y: x * y % p}
+    if field == 0:
+        ops.update({4: lambda x, y: (x << 32) % p, 5: lambda x, y: (x << 64) % p, 6: lambda x, y: (x << (y % 96)) % p, 7: lambda x, y: (x + ((y & 0x7FFFFFFF) << 64)) % p})
+    for op, f in ops.items():
+        got = ctx.arith_selftest(op, a, b)
+        want = np.array([f(x, y) for x, y in zip(a, b)], dtype=np.uint64)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, f"field {field} op {op}: {len(bad)} mismatches, first a={a[bad[0]]:#x} b={b[bad[0]]:#x} got {int(got[bad[0]]):#x} want {int(want[bad[0]]):#x}"
+    # shift op: every exponent 0..95 on the edge values
+    if field == 0:
+        aa = [x for x in edge for _ in range(96)]
+        ss = [s_ for _ in edge for s_ in range(96)]
+        got = ctx.arith_selftest(6, aa, ss)
+        want = np.array([(x << s_) % p for x, s_ in zip(aa, ss)], dtype=np.uint64)
+        assert (got == want).all()
+    assert ctx.L.ms_arith_selftest(ctx.h, 9, None, None, None, 0) != 0

@@ -154,10 +154,11 @@ def test_device_trace_range_check(mk, field):
     pc.case_device_trace_range_check(mk, field, lambda a: (a.ctypes.data, a))   # emulation: "device" memory is host memory
 
 
-def test_babybear_on_the_round2_tiles(mk, monkeypatch):
-    """BabyBear runs the round-1 NTT tiles by default (they measured faster); MS_NTT_V2=2 puts it on the cooperative round-2 tiles,
-    which must stay exact."""
-    monkeypatch.setenv("MS_NTT_V2", "2")
+@pytest.mark.parametrize("v2", ["1", "0"])
+def test_babybear_on_the_round2_tiles(mk, monkeypatch, v2):
+    """BabyBear runs the cooperative round-2 tiles by default since r03; MS_NTT_V2=0 keeps the round-1 tiles, which stay in the
+    library for single-pass sizes, other blowups and transforms beyond 2^25 non-zero points.  Both must be exact."""
+    monkeypatch.setenv("MS_NTT_V2", v2)
     fresh = lambda f, fresh=False: mk(f, fresh=True)
     pc.case_ntt(fresh, 1, 16)
     pc.case_coset_lde(fresh, 1, 14, 8)
@@ -197,6 +198,22 @@ def test_ntt_fused_tail_full_tiles(mk):
     pc.case_coset_lde(fresh, 0, 20, 8)
 
 
+def test_babybear_full_tiles(mk):
+    """BabyBear on the 2^10-row tiles with three sub-rounds (r03): 64 KiB tiles of 16 columns x 512 threads (plain first pass, later pass with
+    the fused tail) and 32 KiB tiles of the 8 cosets x 256 threads behind the virtual pass - the benchmark's shapes 2^20 and 2^20 -> 2^23."""
+    fresh = lambda f, fresh=False: mk(f, fresh=True)
+    pc.case_ntt(fresh, 1, 20, batch=1)
+    pc.case_coset_lde(fresh, 1, 20, 8)
+    pc.case_ntt(fresh, 1, 21, batch=1)      # + register pass
+
+
 @pytest.mark.parametrize("field", [0, 1])
 def test_lincomb_shared_sweep(mk, field):
     pc.case_lincomb_shared_sweep(lambda f: mk(f, fresh=True), field)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_arith_selftest(mk, field):
+    """ADVICE r2 / VERDICT r2 #3: the NTT tiles' arithmetic class op by op against big integers (GPU: the exec-masked asm class GLM itself;
+    emulation: the formulas it falls back to - the entry point's plumbing)."""
+    pc.case_arith_selftest(mk, field, nrand=1 << 12)

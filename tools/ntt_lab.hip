@@ -115,6 +115,105 @@ struct GL3 {
   }
 };
 
+// ---- variant 5 (r03): variant 3 with the subtraction's borrow taken from v_subb_co_u32's carry-out (an SGPR pair) instead of a
+// v_cmp_lt_u64: 3 VALU instructions per sub (4), also inside mul_x64.  Two asm statements: the first leaves exec alone.
+struct GL5 : GL3 {
+  static __device__ __forceinline__ u64 sub(u64 a, u64 b) {
+    u32 d0, d1; u64 bm, sv;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %1, %2, %4, %6, vcc"
+        : "=&v"(d0), "=&v"(d1), "=&s"(bm) : "v"(GL::lo(a)), "v"(GL::hi(a)), "v"(GL::lo(b)), "v"(GL::hi(b)) : "vcc");
+    u64 d = GL::mk(d0, d1);
+    asm("s_and_saveexec_b64 %1, %2\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %3\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(d), "=&s"(sv) : "s"(bm), "s"(GL::P) : "scc");
+    return d;
+  }
+  static __device__ __forceinline__ u64 mul_x64(u64 z) {       // z0 * EPS - z1
+    const u64 U = (u64)GL::lo(z) * 0xFFFFFFFFu;
+    u32 d0, d1; u64 bm, sv;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %1, %2, 0, %4, vcc"
+        : "=&v"(d0), "=&v"(d1), "=&s"(bm) : "v"(GL::lo(U)), "v"(GL::hi(U)), "v"(GL::hi(z)) : "vcc");
+    u64 r = GL::mk(d0, d1);
+    asm("s_and_saveexec_b64 %1, %2\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %3\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(r), "=&s"(sv) : "s"(bm), "s"(GL::P) : "scc");
+    return r;
+  }
+  template <int S> static __device__ __forceinline__ u64 mul_pow2(u64 x) {
+    if constexpr (S == 0) return x;
+    else if constexpr (S < 32) return fold(x << S, GL::hi(x) >> (32 - S));
+    else if constexpr (S < 64) return mul_x32(mul_pow2<S - 32>(x));
+    else return mul_x64(mul_pow2<S - 64>(x));
+  }
+};
+// ---- variant 6 (r03): variant 5 under the assumption that EVERY lane of the wave is live (exec == -1 on entry): the masks go straight
+// into exec (s_or_b64 exec / s_mov_b64 exec) and exec is restored with a constant - one scalar instruction less per operation and no
+// dependency of the restore on a saved copy.  Only valid in straight-line, wave-uniform code.
+struct GL6 {
+  static __device__ __forceinline__ u64 add(u64 a, u64 b) {
+    u64 s, sv;
+    asm("v_lshl_add_u64 %0, %2, 0, %3\n\t"
+        "v_cmp_lt_u64 vcc, %0, %2\n\t"
+        "v_cmp_lt_u64 %1, %4, %0\n\t"
+        "s_or_b64 exec, vcc, %1\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %5\n\t"
+        "s_mov_b64 exec, -1"
+        : "=&v"(s), "=&s"(sv) : "v"(a), "v"(b), "s"(GL::P - 1), "s"(GL::EPS) : "vcc", "scc");
+    return s;
+  }
+  static __device__ __forceinline__ u64 sub(u64 a, u64 b) {
+    u32 d0, d1; u64 bm;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %1, %2, %4, %6, vcc"
+        : "=&v"(d0), "=&v"(d1), "=&s"(bm) : "v"(GL::lo(a)), "v"(GL::hi(a)), "v"(GL::lo(b)), "v"(GL::hi(b)) : "vcc");
+    u64 d = GL::mk(d0, d1);
+    asm("s_mov_b64 exec, %1\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %2\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(d) : "s"(bm), "s"(GL::P));
+    return d;
+  }
+  static __device__ __forceinline__ u64 fold(u64 A, u32 h) {
+    u64 sv;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %0\n\t"
+        "v_cmp_lt_u64 %1, %3, %0\n\t"
+        "s_or_b64 exec, vcc, %1\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %4\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(A), "=&s"(sv) : "v"(h), "s"(GL::P - 1), "s"(GL::EPS) : "vcc", "scc");
+    return A;
+  }
+  static __device__ __forceinline__ u64 mul_x32(u64 z) { return fold(z << 32, GL::hi(z)); }
+  static __device__ __forceinline__ u64 mul_x64(u64 z) {
+    const u64 U = (u64)GL::lo(z) * 0xFFFFFFFFu;
+    u32 d0, d1; u64 bm;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %1, %2, 0, %4, vcc"
+        : "=&v"(d0), "=&v"(d1), "=&s"(bm) : "v"(GL::lo(U)), "v"(GL::hi(U)), "v"(GL::hi(z)) : "vcc");
+    u64 r = GL::mk(d0, d1);
+    asm("s_mov_b64 exec, %1\n\t"
+        "v_lshl_add_u64 %0, %0, 0, %2\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(r) : "s"(bm), "s"(GL::P));
+    return r;
+  }
+  template <int S> static __device__ __forceinline__ u64 mul_pow2(u64 x) {
+    if constexpr (S == 0) return x;
+    else if constexpr (S < 32) return fold(x << S, GL::hi(x) >> (32 - S));
+    else if constexpr (S < 64) return mul_x32(mul_pow2<S - 32>(x));
+    else return mul_x64(mul_pow2<S - 64>(x));
+  }
+  static __device__ __forceinline__ u64 mul(u64 a, u64 b) { return GL3::mul(a, b); }
+};
+
 // ---- variant 4: variant 3 with TWO independent operations per asm block (instruction-level parallelism inside one wave:
 // the SGPR round trips of one chain hide behind the other's VALU work), for tiles whose LDS footprint leaves only 2 waves per SIMD
 struct GL4 : GL3 {
@@ -318,6 +417,8 @@ int main() {
 
   check<GLr>("r02 sign-bit GLT (field.hpp)");
   check<GL3>("masked asm");
+  check<GL5>("masked asm, borrow from subb (r03)");
+  check<GL6>("masked asm, full-exec form (r03)");
 
   u64 *d_in, *d_out;
   std::vector<u64> h(4096);
@@ -332,6 +433,13 @@ int main() {
     run<GL1, 5, 0>("r02 radix-32 DIF", d_out, d_in, blocks, 32 * 5);
     run<GL3, 5, 0>("masked-asm radix-32 DIF", d_out, d_in, blocks, 32 * 5);
     run<GL3, 4, 0>("masked-asm radix-16 DIF", d_out, d_in, blocks, 16 * 4);
+    run<GL5, 5, 0>("r03 sub3 radix-32 DIF", d_out, d_in, blocks, 32 * 5);
+    run<GL5, 4, 0>("r03 sub3 radix-16 DIF", d_out, d_in, blocks, 16 * 4);
+    run<GL5, 3, 0>("r03 sub3 radix-8 DIF", d_out, d_in, blocks, 8 * 3);
+    run<GL6, 5, 0>("r03 full-exec radix-32 DIF", d_out, d_in, blocks, 32 * 5);
+    run<GL6, 4, 0>("r03 full-exec radix-16 DIF", d_out, d_in, blocks, 16 * 4);
+    run<GL6, 3, 0>("r03 full-exec radix-8 DIF", d_out, d_in, blocks, 8 * 3);
+    run<GL3, 3, 0>("masked-asm radix-8 DIF", d_out, d_in, blocks, 8 * 3);
     run<GL4, 5, 4>("paired masked-asm radix-32 DIF", d_out, d_in, blocks, 32 * 5);
     run<GL4, 4, 4>("paired masked-asm radix-16 DIF", d_out, d_in, blocks, 16 * 4);
     run<GL3, 4, 3>("masked-asm general multiply (16 values)", d_out, d_in, blocks, 16);
