@@ -138,13 +138,14 @@ class Lanes:
     host-mirror Stark each.  io=False: traces resident in HBM, FRI proofs left in HBM.  io=True: every proof uploads its trace
     from page-locked host memory and reads the FRI proof back into page-locked host memory."""
 
-    def __init__(self, field, log_rows, blowup, inflight, device_index, dev, seed0=2, io=False, lib=None):
+    def __init__(self, field, log_rows, blowup, inflight, device_index, dev, seed0=2, io=False, lib=None, io_mode="async"):
         import numpy as np
         import torch
         import mini_stark_amd as ms
         from mini_stark_amd.stark import StarkConfig, fibonacci_air
         from mini_stark_amd.host import HostStark
-        self.ms, self.io, self.n = ms, io, inflight
+        self.ms, self.io, self.n, self.io_mode = ms, io, inflight, io_mode
+        self.samples = [set() for _ in range(inflight)]
         steps = (1 << log_rows) - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
         self.ctxs = [ms.Context(field, device=device_index, lib_path=lib) for _ in range(inflight)]
         self.tts = [fibonacci_air(c, steps, secret_b=seed0 + i) for i, c in enumerate(self.ctxs)]
@@ -163,10 +164,19 @@ class Lanes:
 
     def _prove_n(self, i, n):
         ptr = None if self.io else self.d_traces[i].data_ptr()
-        for _ in range(n):   # io: the read-back of proof k (copy stream) overlaps the first stages of proof k + 1; the last one is waited for below
-            self.ctxs[i].check(self.starks[i].prove_raw(self.tts[i], trace_device_ptr=ptr, read_fri_proof="async" if self.io else False))
-        if self.io:
+        for k in range(n):
+            # io, mode "into" (default): the query-phase kernels write the FRI proof straight into the mirror's page-locked slot (ms_fri_query_into) - it is
+            # complete when prove returns, and EVERY proof is touched on the host (one word per page) before its slot is reused two proofs later.
+            # io, mode "async": the read-back of proof k (copy stream) overlaps the first stages of proof k + 1; proof k is sampled from the mirror's OTHER
+            # slot after prove k + 1 returned (two proof slots: ADVICE r2), the last one after the final wait.
+            self.ctxs[i].check(self.starks[i].prove_raw(self.tts[i], trace_device_ptr=ptr, read_fri_proof=self.io_mode if self.io else False))
+            if self.io and self.io_mode == "into":
+                self.samples[i].add(self.starks[i].blob_sample(0))
+            elif self.io and k:
+                self.samples[i].add(self.starks[i].blob_sample(1))
+        if self.io and self.io_mode != "into":
             self.ctxs[i].check(self.starks[i].wait_proof())
+            self.samples[i].add(self.starks[i].blob_sample(0))
         self.last[i] = self.starks[i].last_proof(read_fri_proof=False)
 
     def run(self, n):  # n steps = n proofs on each lane (ctypes releases the GIL inside the library)
@@ -279,6 +289,8 @@ def main():
     ap.add_argument("--field", type=int, default=0, help="0 Goldilocks, 1 BabyBear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (2^24 rows, BabyBear, NTT-only, I/O-inclusive) of the N = 1 run")
+    ap.add_argument("--no-cpu-2p24", action="store_true", help="skip the CPU baseline's second sample: one 2^24-row proof (the size north_star's >= 10x target is stated on) on the "
+                                                              "oracle with OpenMP, ~2-3 minutes of host time (cpu_baseline.at_2p24)")
     ap.add_argument("--cpu-log-rows", type=int, default=20, help="size of the CPU baseline's sample proof (default: the benchmark size itself, no extrapolation)")
     ap.add_argument("--inflight", type=int, default=None, help="independent proofs in flight per GPU (one ms_ctx + HIP stream each); a step = this many proofs (default: 8 up to 2^20 rows, fewer above)")
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
@@ -492,9 +504,9 @@ def main():
                 except Exception as e:  # noqa: BLE001 - an extra leg must not take the headline down
                     extra[name] = {"error": f"{type(e).__name__}: {e}"}
 
-            def proofs_leg(field, log_rows, steps, warmup, inflight=None, io=False):
+            def proofs_leg(field, log_rows, steps, warmup, inflight=None, io=False, io_mode="async"):
                 infl = inflight or default_inflight(log_rows)
-                ln = Lanes(field, log_rows, args.blowup, infl, local_rank, dev, io=io)
+                ln = Lanes(field, log_rows, args.blowup, infl, local_rank, dev, io=io, io_mode=io_mode)
                 el = ln.timed(grp, steps, warmup)
                 lat = None
                 if not io:
@@ -502,12 +514,57 @@ def main():
                 r = {"value": steps * infl / el, "unit": "proofs/s", "ms_per_proof_in_flight": el / (steps * infl) * 1e3, "in_flight": infl, "steps": steps, "rounds": ln.cfg.rounds}
                 if lat is not None:
                     r["ms_single_proof_latency"] = lat
+                if io:   # every lane proves the same trace over and over: one distinct non-zero sample per lane = every proof arrived whole
+                    r["every_proof_sampled_on_host"] = all(len(sm) == 1 and 0 not in sm for sm in ln.samples)
                 ln.close()
                 return r
             leg("goldilocks_2p24_rows", lambda: dict(proofs_leg(0, 24, 4, 1), workload="BASELINE configs[3] per GPU: Fibonacci AIR, Goldilocks, 2^24 rows, blowup 8 (L = 2^27, ~25 GiB resident per proof)"))
             leg("babybear_fp4_2p20_rows", lambda: dict(proofs_leg(1, 20, 10, 2), workload="BASELINE configs[2]: Fibonacci AIR, BabyBear + quartic extension, 2^20 rows, blowup 8 (u32 storage)"))
-            leg("value_with_io", lambda: dict(proofs_leg(0, 20, 10, 2, io=True), workload="configs[1] with the boundary's I/O inside the timed region: every proof uploads its 24 MiB trace from page-locked "
-                                              "host memory and reads its ~64 MiB FRI proof back into page-locked host memory (PCIe Gen5 x16; ms_fri_proof_read_async: the read-back of a lane's proof k runs on its copy stream while proof k + 1 starts, every read-back finished inside the timed region), overlapped across the in-flight lanes"))
+            leg("value_with_io", lambda: dict(proofs_leg(0, 20, 10, 2, io=True, io_mode="async"), workload="configs[1] with the boundary's I/O inside the timed region: every proof uploads its 24 MiB trace "
+                                              "from page-locked host memory and its ~64 MiB FRI proof is copied into page-locked host memory by ms_fri_proof_read_async on the lane's copy stream while proof k + 1 "
+                                              "starts; the host mirror keeps two proof slots, proof k is touched on the host (one word per page) after prove k + 1 returned, every read-back finished inside the timed region"))
+            leg("value_with_io_blocking_readback", lambda: dict(proofs_leg(0, 20, 10, 2, io=True, io_mode=True), workload="the same with a blocking ms_fri_proof_read at the end of every proof"))
+            leg("value_with_io_kernels_write_host", lambda: dict(proofs_leg(0, 20, 10, 2, io=True, io_mode="into"), workload="the same with ms_fri_query_into: the query-phase kernels store the FRI proof straight into "
+                                              "page-locked host memory (no copy).  Measured r03: SLOWER (the 64 MiB cross PCIe as stores of kernels whose waves hold their CUs meanwhile; coherent or non-coherent "
+                                              "pinned memory alike) - kept as an API for device-memory destinations, not used as the read-back path"))
+            leg("single_proof", lambda: dict(proofs_leg(0, 20, 30, 4, inflight=1), workload="configs[1] with ONE proof in flight (latency configuration): 1 / value = the time of one Stark::prove"))
+
+            def wide_air():
+                # BASELINE configs[4] on one GPU: 64 trace columns + 64 transition polynomials (c = 128), Goldilocks, 2^22 rows, blowup 8; linear transitions
+                # (degree-3 constraints are not expressible in the reference: quirk Q1); challenges from SplitMix64; one proof in flight, trace resident in HBM
+                from mini_stark_amd.synthetic import SplitMix64
+                P, lr, w = 2**64 - 2**32 + 1, 22, 64
+                N = 1 << lr
+                rs = np.random.RandomState(7)
+                d_tr = torch.from_numpy((rs.randint(0, 2**62, size=(N, w), dtype=np.int64))).to(dev)   # < 2^62 < p: canonical
+                c2 = ms.Context(0, device=local_rank)
+                rng = SplitMix64(5)
+                combos = [([rng.next() % P or 1, rng.next() % P, P - 1], [j, (j + 1) % w, (j + 7) % w]) for j in range(w)]
+                rounds = lr + 3
+
+                def one():
+                    r2 = SplitMix64(6)
+                    c2.check(c2.trace_commit_device(d_tr.data_ptr(), N, w, 2 * w)[0]); c2.check(c2.interpolate())
+                    for sc, idx in combos:
+                        c2.check(c2.polys_lincomb(sc, idx))
+                    c2.check(c2.lde_commit(args.blowup, r2.next() % P or 3, 2 * w)[0]); c2.check(c2.mix(r2.next() % P))
+                    c2.check(c2.eval_ext(np.array([r2.next() % P, r2.next() % P], dtype=np.uint64))[0])
+                    c2.check(c2.fri_begin(args.blowup, rounds)[0])
+                    for _ in range(1, rounds):
+                        c2.check(c2.fri_deep([r2.next() % P, r2.next() % P])[0]); c2.check(c2.fri_fold_commit([r2.next() % P, r2.next() % P])[0])
+                    c2.check(c2.fri_query([r2.next()], read=False)[0])
+                one()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    one()
+                c2.synchronize()
+                el = (time.perf_counter() - t0) / 2
+                c2.close()
+                return {"value": 1.0 / el, "unit": "proofs/s", "ms_per_proof": el * 1e3, "in_flight": 1, "steps": 2, "rounds": rounds,
+                        "workload": "BASELINE configs[4] per GPU: wide synthetic AIR, 64 trace columns + 64 linear transition polynomials (c = 128), Goldilocks, 2^22 rows, blowup 8 "
+                                    "(32 GiB LDE matrix, 2^25 leaf messages of ~2.5 KB)"}
+            leg("wide_air_2p22", wide_air)
 
             def ntt_only():
                 res = {}
@@ -515,8 +572,8 @@ def main():
                 try:
                     from mini_stark_amd.stark import fibonacci_air
                     stream = torch.cuda.Stream(device=dev)
-                    for lr, reps in ((20, 20), (24, 3)):
-                        c2 = ms.Context(0, device=local_rank)
+                    for fld, lr, reps in ((0, 20, 20), (0, 24, 3), (1, 20, 20), (1, 22, 8)):
+                        c2 = ms.Context(fld, device=local_rank)
                         c2.set_stream(stream.cuda_stream)
                         tt = fibonacci_air(c2, (1 << lr) - 1)
                         with torch.cuda.stream(stream):
@@ -531,9 +588,11 @@ def main():
                             e1.record(stream)
                         torch.cuda.synchronize()
                         ms_per = e0.elapsed_time(e1) / reps
-                        alg = 6 * ((1 << lr) + (1 << lr) * args.blowup) * 8
-                        res[f"coset_lde_6x2^{lr}_to_2^{lr + 3}"] = {"ms": ms_per, "alg_GBps": alg / ms_per / 1e6, "frac_of_hbm_peak": alg / ms_per / 1e6 / HBM_PEAK_GBS,
-                                                                    "alg_bytes": alg, "what": "scale + NTT passes of six columns, device resident, HIP events on the launching stream"}
+                        sz = 8 if fld == 0 else 4            # bytes per base element as stored on the device
+                        alg = 6 * ((1 << lr) + (1 << lr) * args.blowup) * sz
+                        res[("" if fld == 0 else "babybear_") + f"coset_lde_6x2^{lr}_to_2^{lr + 3}"] = {
+                            "ms": ms_per, "alg_GBps": alg / ms_per / 1e6, "frac_of_hbm_peak": alg / ms_per / 1e6 / HBM_PEAK_GBS, "alg_bytes": alg, "element_bytes": sz,
+                            "what": "scale + NTT passes of six columns, device resident, HIP events on the launching stream"}
                         c2.close()
                 finally:
                     del os.environ["MS_LDE_LINEAR"]
@@ -575,6 +634,23 @@ def main():
             if best is not None:
                 out["cpu_baseline"]["all_cores"] = {"value": 1.0 / (best[0] * scale), "unit": "proofs/s", "cores": best[1], "kind": "port", "host_cpus": ncpu,
                                                     "sample": f"same 2^{cl}-row proof with OpenMP x{best[1]} over the port's independent loops (best of the thread counts tried) took {best[0]:.2f} s"}
+            # the size north_star states its >= 10x target on: ONE 2^24-row Goldilocks proof on the port with OpenMP (context for the reader; the ratio is not a quality claim)
+            if not args.no_cpu_2p24 and args.field == 0 and args.log_rows == 20 and not args.no_extras:
+                try:
+                    from mini_stark_amd.host import fibonacci_rows_native
+                    nthr = best[1] if best is not None else 1
+                    orc.set_threads(nthr)
+                    tr24 = fibonacci_rows_native(2**64 - 2**32 + 1, 1 << 24, (1 << 24) - 1)
+                    c0 = time.perf_counter()
+                    pc.drive(orc.Session(0), 0, tr24, args.blowup, 0, seed=1, q_ood=1, read_big=False, fixed_betas=(3,))   # rounds 27, 1 OOD query, 1 FRI query: StarkConfig at 2^24 rows
+                    c24 = time.perf_counter() - c0
+                    orc.set_threads(1)
+                    gpu24 = (out.get("extra") or {}).get("goldilocks_2p24_rows", {}).get("value")
+                    out["cpu_baseline"]["at_2p24"] = {"value": 1.0 / c24, "unit": "proofs/s", "cores": nthr, "kind": "port",
+                                                      "sample": f"one 2^24-row Goldilocks proof (BASELINE configs[3] per GPU: rounds 27, 1 OOD query, 1 FRI query) on the oracle with OpenMP x{nthr} took {c24:.1f} s",
+                                                      "gpu_same_size_proofs_per_s": gpu24, "gpu_over_cpu": (gpu24 * c24) if gpu24 else None}
+                except Exception as e:  # noqa: BLE001 - a reported baseline must not take the line down
+                    out["cpu_baseline"]["at_2p24"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     grp.close()
 

@@ -29,6 +29,7 @@ extern "C" {
     // ---- one proof over the GPUs of a node
     pub fn ms_set_shard(ctx: *mut ms_ctx, rank: c_int, world: c_int, d_send: *mut c_void, d_recv: *mut c_void, cap_bytes: usize,
                         f: ms_exchange_fn, user: *mut c_void) -> c_int;
+    pub fn ms_shard_slice_layout(ctx: *mut ms_ctx, offset: *mut usize, stride: *mut usize) -> c_int;
     pub fn ms_rccl_unique_id(out: *mut u8 /* [128] */) -> c_int;
     pub fn ms_set_shard_rccl(ctx: *mut ms_ctx, rank: c_int, world: c_int, unique_id: *const u8 /* [128] */, cap_bytes: usize) -> c_int;
     pub fn ms_rccl_selftest(ctx: *mut ms_ctx) -> c_int;

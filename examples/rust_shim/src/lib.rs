@@ -1,7 +1,10 @@
 //! Safe wrapper over `ffi`: one method per transcript-delimited stage of `Stark::prove` (src/starks.rs:59-169) and
 //! `Fri::prove` (src/fri.rs:53-189).  `prove_gpu` in INTEGRATION.md §4 is written against this type; the Fiat–Shamir
 //! transcript (nimue) stays on the Rust side of the boundary.
+pub mod convert;
 pub mod ffi;
+// tree.rs, fri_proof.rs and prove.rs are CHILD modules of the reference's merkle.rs / fri.rs / starks.rs (they build types whose
+// fields are private there); their headers say where each one goes.  This file and ffi.rs / convert.rs form `crate::gpu`.
 use ffi::*;
 use std::ffi::CStr;
 

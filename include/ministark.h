@@ -80,13 +80,17 @@ void ms_pinned_free(void* p);
  *   ALL_TO_ALL         send = world chunks of `bytes` (chunk p goes to rank p), recv = world chunks (chunk p from rank p)
  *   ALL_GATHER         send = `bytes`, recv = world * `bytes` in rank order
  *   ALL_REDUCE_MIN_U64 / ALL_REDUCE_SUM_U8   in place on send, `bytes` in total
+ *   ALL_TO_ALL_SLICE   one slice of a commitment's digest all-to-all (large commitments are hashed in MS_SHARD_SLICES slices so that the digests of a
+ *                      slice travel while the next one is hashed): peer p's piece is the `bytes` at offset + p * stride of BOTH buffers, with
+ *                      (offset, stride) from ms_shard_slice_layout(ctx, ..) inside the callback
  * The library has synchronised its stream before the call; `fn` returns 0 once the result is visible to the device.
  * Commitments with fewer than MS_SHARD_MIN_LEAVES (env, default 32768) leaf groups stay replicated.
  * world must be a power of two; world = 1 switches sharding off.  ms_lde_read / ms_fri_round_codeword_read
  * are not available for sharded commitments (each rank holds its part only). */
-typedef enum { MS_XCHG_ALL_TO_ALL = 0, MS_XCHG_ALL_GATHER = 1, MS_XCHG_ALL_REDUCE_MIN_U64 = 2, MS_XCHG_ALL_REDUCE_SUM_U8 = 3 } ms_xchg_op;
+typedef enum { MS_XCHG_ALL_TO_ALL = 0, MS_XCHG_ALL_GATHER = 1, MS_XCHG_ALL_REDUCE_MIN_U64 = 2, MS_XCHG_ALL_REDUCE_SUM_U8 = 3, MS_XCHG_ALL_TO_ALL_SLICE = 4 } ms_xchg_op;
 typedef int (*ms_exchange_fn)(void* user, int op, size_t bytes);
 int ms_set_shard(ms_ctx* ctx, int rank, int world, void* d_send, void* d_recv, size_t cap_bytes, ms_exchange_fn fn, void* user);
+int ms_shard_slice_layout(ms_ctx* ctx, size_t* offset, size_t* stride);
 /* The production form: the library runs the four collectives itself with RCCL (ncclSend/ncclRecv in one group, ncclAllGather,
  * ncclAllReduce) ON THE CONTEXT'S STREAM - stream-ordered with the kernels on both sides, no stream synchronisation, no host
  * callback - and owns the two exchange buffers (`cap_bytes` each: 32 * leaf groups of the largest commitment / world + 4 MiB).

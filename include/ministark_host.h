@@ -57,6 +57,8 @@ size_t msh_prev_proof_fri_roots(const msh_stark* h, uint8_t* out, size_t cap);
 size_t msh_prev_proof_fri_blob(const msh_stark* h, uint8_t* out, size_t cap);
 /* FNV-1a (64-bit words) over the FRI blob of the last (which = 0) / previous (which = 1) proof, read in place from its page-locked slot */
 uint64_t msh_proof_blob_checksum(const msh_stark* h, int which);
+/* the same over one 64-bit word per `stride_bytes` plus the last word */
+uint64_t msh_proof_blob_sample(const msh_stark* h, int which, size_t stride_bytes);
 /* Stark::verify (starks.rs:171-235) on the CPU.  A PARITY MIRROR of the reference's verifier, including what it does NOT bind
  * (INTEGRATION.md "verifier"): 1 accepted, 0 rejected, < 0 malformed. */
 int msh_stark_verify(const msh_stark* h, const uint64_t* constrains, size_t c, size_t N, const uint8_t* arthur, size_t arthur_len, const uint8_t* trace_commit,

@@ -375,6 +375,9 @@ template <class F, int E, bool LAZY = false> struct LeafHashKernel {
     size_t ngroups;
     u32* nodes;  // 8 words per digest, standard byte order in memory
     u32* ovf_count; u32* ovf; u32 ovf_cap;  // deferred pad-only blocks: OVF_LISTS counters, and lists of ovf_cap entries of OVF_WORDS words (group, message bits)
+    // run_len != 0: the launch hashes `ngroups` groups that are RUNS of run_len consecutive groups, run_stride apart, from g_first on (one slice of
+    // every peer's chunk of a sharded commitment: its digests can travel while the next slice is hashed)
+    size_t g_first; u32 run_len, run_stride;
   };
   static constexpr int MAX_BYTES = F::MAX_DIGITS + Affix<E>::MAX_BYTES;  // appended between two drains
   static constexpr int MAXW = (3 + MAX_BYTES + 3) / 4 + 1;               // words one iteration can touch past the write position
@@ -383,8 +386,9 @@ template <class F, int E, bool LAZY = false> struct LeafHashKernel {
   static MS_HD int nphases(const Params&) { return 1; }
   static MS_HD size_t lds_bytes() { return (size_t)NWORDS * THREADS * sizeof(u32); }
   static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char* lds) {
-    const size_t g = (size_t)bx * nthreads + tid;
+    size_t g = (size_t)bx * nthreads + tid;
     if (g >= p.ngroups) return;
+    if (p.run_len) g = p.g_first + (g / p.run_len) * (size_t)p.run_stride + g % p.run_len;
     Stream s; s.init(reinterpret_cast<u32*>(lds), tid);
     size_t f = g * p.lpn;
     size_t row = f / p.width; u32 col = (u32)(f - row * p.width);

@@ -62,6 +62,7 @@ struct CtxBase {
   virtual int set_shard(int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) = 0;
   virtual int set_shard_rccl(int rank, int world, const u8* unique_id, size_t cap) = 0;
   virtual int shard_stats(u64* out) = 0;
+  virtual int shard_slice_layout(size_t* off, size_t* stride) = 0;
   virtual int rccl_selftest() = 0;
   virtual int trace_commit(const u64* trace, bool on_device, size_t N, size_t w, size_t lpn, u8* root) = 0;
   virtual int interpolate() = 0;
@@ -105,8 +106,9 @@ template <class F> struct Ctx : CtxBase {
 
   int device = 0, zae = 1, trace_mont = 0;
   int lde_linear = 1;  // MS_LDE_LINEAR=0 disables the linear-provenance shortcut of lde_compute (A/B measurements)
-  int lde_multi = 0;   // MS_LDE_MULTI=1: the linear LDE columns in shared sweeps (LincombMultiKernel).  Measured (r02): 45 us less per proof alone (6 column
-                       // transfers instead of 10), but 248 -> 240 proofs/s with 8 proofs in flight (five interleaved runs each), so it is off by default
+  int lde_multi = -1;  // MS_LDE_MULTI: the linear LDE columns in shared sweeps (LincombMultiKernel).  -1 (default): for AIRs of >= 16 polynomials (the wide AIR: 112
+                       // launches become 16 and the LDE commit 108.7 -> 105.6 ms, r03); 0 / 1 force it.  Narrow AIRs keep the one-by-one kernel: measured (r02) 45 us less
+                       // per Fibonacci proof alone, but 248 -> 240 proofs/s with 8 proofs in flight (five interleaved runs each)
   int tree_top_parents = msmerkle::THREADS;  // MS_TREE_TOP: levels of at most this many parents are walked by one workgroup in one launch (measured: 256 beats 1024 by 3 % in latency)
   int leaf_lazy_min = 16;  // MS_LEAF_LAZY_MIN: leaf groups of at least this many base limbs use the wave-synchronous two-block leaf kernel
   int fri_pointwise = 1;  // MS_FRI_POINTWISE=0: codewords of FRI rounds >= 1 by NTT of the round polynomial instead of the evaluation-domain fold
@@ -144,6 +146,37 @@ template <class F> struct Ctx : CtxBase {
     }
     CK(msrt::sync(stream));
     if (xfn(xuser, op, bytes)) return fail(MS_ERR_HIP, "exchange callback failed");
+    return 0;
+  }
+  // one slice of a sliced digest all-to-all: peer r's piece at offset `off + r * stride`, `bytes` long, in both exchange buffers
+  int shard_slices = 4; size_t shard_slice_min = 1024;
+  size_t xl_off = 0, xl_stride = 0;
+  msrt::Stream* comm_stream = nullptr; std::vector<msrt::Event*> ev_hash, ev_xchg;
+  int shard_slice_layout(size_t* off, size_t* stride) override { if (!off || !stride) return fail(MS_ERR_ARG, "shard_slice_layout"); *off = xl_off; *stride = xl_stride; return MS_OK; }
+  int exchange_slice(size_t off, size_t stride, size_t bytes, int sl, int S) {
+    if (sl == 0) xstat[0]++;                        // one all-to-all per commitment, whatever the number of slices
+    xstat[4] += bytes * (size_t)(sh_world - 1);
+    if (rccl_comm) {
+      msrt::Rccl& R = msrt::Rccl::get();
+      if (!comm_stream) CK(msrt::stream_create(&comm_stream));
+      while ((int)ev_hash.size() < S) { msrt::Event* a; msrt::Event* b; CK(msrt::event_create(&a)); CK(msrt::event_create(&b)); ev_hash.push_back(a); ev_xchg.push_back(b); }
+      CK(msrt::event_record(ev_hash[sl], stream));                 // slice hashed (incl. its deferred pad-only blocks)
+      CK(msrt::stream_wait_event(comm_stream, ev_hash[sl]));
+      int e = R.group_start();
+      for (int r = 0; r < sh_world && !e; r++) {
+        e = R.send(xs + off + (size_t)r * stride, bytes, 1 /* ncclUint8 */, r, rccl_comm, comm_stream);
+        if (!e) e = R.recv(xr + off + (size_t)r * stride, bytes, 1, r, rccl_comm, comm_stream);
+      }
+      const int e2 = R.group_end();
+      if (!e) e = e2;
+      if (e) { err = std::string("RCCL error ") + std::to_string(e) + (R.err_string ? std::string(": ") + R.err_string(e) : std::string()); return MS_ERR_HIP; }
+      CK(msrt::event_record(ev_xchg[sl], comm_stream));
+      if (sl == S - 1) CK(msrt::stream_wait_event(stream, ev_xchg[sl]));   // the communication stream runs in order: the last slice's event covers all of them
+      return 0;
+    }
+    CK(msrt::sync(stream));
+    xl_off = off; xl_stride = stride;
+    if (xfn(xuser, MS_XCHG_ALL_TO_ALL_SLICE, bytes)) return fail(MS_ERR_HIP, "exchange callback failed");
     return 0;
   }
   void drop_rccl() {
@@ -622,7 +655,8 @@ template <class F> struct Ctx : CtxBase {
   }
   // leaf-group digests of `ngroups` groups into `out`: LeafHashKernel + the compacted pad-only blocks it deferred
   template <int EL>
-  int leaf_hash(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, size_t lpn, size_t ngroups, u32* out) {
+  int leaf_hash(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, size_t lpn, size_t ngroups, u32* out,
+                size_t g_first = 0, u32 run_len = 0, u32 run_stride = 0) {
     if (ngroups >> 32) return fail(MS_ERR_SHAPE, "more than 2^32 leaf groups");
     // deferred pad-only blocks: OVF_LISTS lists, list l fed by the workgroups bx = l (mod OVF_LISTS); capacity = all their threads
     const size_t nwg = grid1(ngroups, msmerkle::THREADS), lists = msmerkle::OVF_LISTS;
@@ -634,12 +668,14 @@ template <class F> struct Ctx : CtxBase {
     lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
     lp.width = width; lp.lpn = (u32)lpn; lp.zero_as_empty = zae; lp.ngroups = ngroups; lp.nodes = out;
     lp.ovf_count = reinterpret_cast<u32*>(counters); lp.ovf = d_ovf.as<u32>(); lp.ovf_cap = (u32)cap;
+    lp.g_first = g_first; lp.run_len = run_len; lp.run_stride = run_stride;
     next_bytes = (double)ngroups * (lpn * EL * sizeof(T) + 32);
     if (lpn * EL >= (size_t)leaf_lazy_min) {  // long messages (wide rows): the two-block buffer that compresses wave-synchronously
       typedef msmerkle::LeafHashKernel<F, EL, true> LK;
       typename LK::Params ll;
       ll.base = lp.base; ll.col_stride = lp.col_stride; ll.row_stride = lp.row_stride; ll.limb_stride = lp.limb_stride; ll.width = lp.width; ll.lpn = lp.lpn;
       ll.zero_as_empty = lp.zero_as_empty; ll.ngroups = lp.ngroups; ll.nodes = lp.nodes; ll.ovf_count = lp.ovf_count; ll.ovf = lp.ovf; ll.ovf_cap = lp.ovf_cap;
+      ll.g_first = g_first; ll.run_len = run_len; ll.run_stride = run_stride;
       CK(run<LK>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, LK::lds_bytes(), ll));
     } else
     CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
@@ -694,8 +730,20 @@ template <class F> struct Ctx : CtxBase {
     if (Mloc * 32 > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small for the sharded commitment (need 32 * leaf groups / world bytes)");
     const size_t sub_nodes = 2 * Mloc - 1, top_nodes = 2 * W - 1;
     if (nodes.ensure((sub_nodes + top_nodes) * 32)) return fail(MS_ERR_NOMEM, "merkle nodes");
-    RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, reinterpret_cast<u32*>(xs))));
-    RQ(exchange(MS_XCHG_ALL_TO_ALL, per * 32));
+    // The digest all-to-all overlaps the leaf hashing (r03): the local groups are hashed in `S` slices - slice s = the s-th part of EVERY peer's chunk - and
+    // the digests of slice s travel (RCCL: on the context's communication stream, ordered by events) while slice s + 1 is hashed.  MS_SHARD_SLICES (4) /
+    // MS_SHARD_SLICE_MIN (1024 groups per peer and slice; below that the commitment goes out in one piece).
+    const size_t S = (shard_slices > 1 && per % (size_t)shard_slices == 0 && per / (size_t)shard_slices >= shard_slice_min) ? (size_t)shard_slices : 1;
+    if (S == 1) {
+      RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, reinterpret_cast<u32*>(xs))));
+      RQ(exchange(MS_XCHG_ALL_TO_ALL, per * 32));
+    } else {
+      const size_t q = per / S;
+      for (size_t sl = 0; sl < S; sl++) {
+        RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, W * q, reinterpret_cast<u32*>(xs), sl * q, (u32)q, (u32)per)));
+        RQ(exchange_slice(sl * q * 32, per * 32, q * 32, (int)sl, (int)S));
+      }
+    }
     msmerkle::InterleaveDigestsKernel::Params ik{reinterpret_cast<const msmerkle::uint4_t*>(xr), reinterpret_cast<msmerkle::uint4_t*>(nodes.p), per, (u32)W};
     CK(run<msmerkle::InterleaveDigestsKernel>(K_IO, grid1(Mloc * 2, msmerkle::InterleaveDigestsKernel::THREADS), 1, msmerkle::InterleaveDigestsKernel::THREADS, 0, ik));
     RQ(inner_levels(nodes.as<u32>(), Mloc, 2, false));
@@ -767,6 +815,8 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_FAST_MIN")) ntt_fast_min = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
     if (const char* e = getenv("MS_SHARD_MIN_LEAVES")) { long v = atol(e); if (v >= 1) shard_min_leaves = (size_t)v; }
+    if (const char* e = getenv("MS_SHARD_SLICES")) { int v = atoi(e); if (v >= 1 && v <= 64) shard_slices = v; }
+    if (const char* e = getenv("MS_SHARD_SLICE_MIN")) { long v = atol(e); if (v >= 1) shard_slice_min = (size_t)v; }
     CK(msrt::set_device(dev));
     CK(msrt::stream_create(&own_stream));
     stream = own_stream;
@@ -779,6 +829,9 @@ template <class F> struct Ctx : CtxBase {
     for (auto& kv : plans) { kv.second->tw_lo.release(); kv.second->tw_hi.release(); kv.second->vtw.release(); kv.second->w0.release(); for (auto& b : kv.second->w_r) b.release(); delete kv.second; }
     drop_rccl();
     if (copy_pending) msrt::event_sync(ev_copy);
+    for (msrt::Event* e : ev_hash) msrt::event_destroy(e);
+    for (msrt::Event* e : ev_xchg) msrt::event_destroy(e);
+    if (comm_stream) msrt::stream_destroy(comm_stream);
     if (ev_blob) msrt::event_destroy(ev_blob);
     if (ev_copy) msrt::event_destroy(ev_copy);
     if (copy_stream) msrt::stream_destroy(copy_stream);
@@ -916,7 +969,7 @@ template <class F> struct Ctx : CtxBase {
     for (size_t i = 0; i < c; i++) {
       const Lin& li = poly_lin[i];
       if (li.idx.empty()) continue;
-      bool simple = lde_multi && li.idx.size() <= (size_t)mspoly::LCM_SRC;
+      bool simple = (lde_multi < 0 ? c >= 16 : lde_multi != 0) && li.idx.size() <= (size_t)mspoly::LCM_SRC;
       for (int ix : li.idx) if (ix < 0 || (size_t)ix >= c || !poly_lin[ix].idx.empty()) simple = false;   // a source that is itself a linear column: keep the order
       if (simple) {
         for (int attempt = 0; attempt < 2; attempt++) {
@@ -1708,6 +1761,7 @@ int ms_set_shard_rccl(ms_ctx* ctx, int rank, int world, const uint8_t unique_id[
 }
 int ms_rccl_selftest(ms_ctx* ctx) { if (!ctx) return MS_ERR_ARG; B(ctx)->bind_device(); return B(ctx)->rccl_selftest(); }
 int ms_shard_stats(ms_ctx* ctx, uint64_t out[8]) { if (!ctx) return MS_ERR_ARG; return B(ctx)->shard_stats(out); }
+int ms_shard_slice_layout(ms_ctx* ctx, size_t* offset, size_t* stride) { if (!ctx) return MS_ERR_ARG; return B(ctx)->shard_slice_layout(offset, stride); }
 int ms_synchronize(ms_ctx* ctx) { if (!ctx) return MS_ERR_ARG; B(ctx)->bind_device(); return B(ctx)->synchronize(); }
 
 int ms_is_power_of_two(uint64_t n) { return is_pow2(n) ? 1 : 0; }

@@ -484,7 +484,19 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 
   // tile | w_r [R] | store twiddle of every tile row [R] (filled in the load phase, while the tile's global loads are in flight)
   static MS_HD size_t lds_bytes() { return ((size_t)R * C + 2 * R) * sizeof(T); }
-  static MS_HD int prow(int row) { return row ^ ((row >> BL) & 3); }
+  // r03, SHIFT1: the SECOND sub-round boundary of a three-sub-round Goldilocks tile multiplies by w_(2^(B1+BL))^(e * lo), a root of order <= 64, i.e.
+  // a power of two (w_64 = 2^39 for the reference's generator) - so if every lane of a wave works on the same `lo` the multiplication is a SHIFT by a
+  // wave-uniform amount (one of 2^BL compile-time variants picked by a scalar branch): 6.7 VALU instructions per element instead of 19 * 7/8.  The
+  // sub-round's items are therefore mapped wave = lo, lane = (top digit, column); the lanes of a wave then read rows 2^(B1+BL) apart, which the second
+  // XOR term of the row swizzle (the low two bits of the top digit) spreads over the banks again (two lanes per bank: the minimum for 512 bytes).
+#ifndef MS_NTT_SHIFT1
+#define MS_NTT_SHIFT1 1   // 1: plain first pass and later passes (measured r03: later pass 83 -> 79 VALU instructions per element, 239 -> 234 us per six-column launch);
+                          // 2: also behind the virtual pass (126.7 -> 124.9 instructions, but 296 -> 303 us: bank conflicts of the bigger store table + scalar work); 0: off
+#endif
+  static constexpr bool SHIFT1 = MS_NTT_SHIFT1 != 0 && (MODE != 2 || MS_NTT_SHIFT1 == 2) && F::ID == 0 && NSUB == 3 && (TH / 64) == (1 << DG::slo(1)) && ((C << DG::bits(0)) % 64) == 0 && (64 % C) == 0 &&
+                                 DG::bits(0) >= 2 && DG::bits(1) >= 2 && DG::bits(1) + BL <= 6 &&
+                                 (MODE != 2 || ((C << BL) << DG::bits(1)) <= R / 2);   // behind the virtual pass the store table [E1][E2][c] must fit half the row-twiddle region
+  static MS_HD int prow(int row) { return row ^ ((row >> BL) & 3) ^ (SHIFT1 ? ((row >> DG::slo(0)) & 3) : 0); }
   static MS_HD int tix(int row, int c) { return prow(row) * C + c; }
   static MS_HD int mode_of(const Params& p) { return p.log_r0 ? 2 : (p.log_Rp == 0 ? 0 : 1); }
   static MS_HD bool applicable(const Params& p) {
@@ -522,9 +534,11 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       const int lo = g & (Q - 1), R0 = ((g >> SLO) << (SLO + B)) | lo;     // row of t = 0
       // physical row of element t = R0 + t*Q under the swizzle: up to four bases selected by the compile-time (t & 3)
       T* base[4];
-      if constexpr (SLO >= BL + 2) { base[0] = tile + ((R0 ^ ((R0 >> BL) & 3)) * C + c); base[1] = base[2] = base[3] = base[0]; }
-      else if constexpr (SLO == 0) { const int h3 = (R0 >> BL) & 3; for (int k = 0; k < 4; k++) base[k] = tile + ((R0 + (k ^ h3)) * C + c); }
-      else { for (int k = 0; k < 4; k++) base[k] = tile + ((R0 ^ k) * C + c); }                // SLO == BL: the swizzle term is t & 3
+      static_assert(!SHIFT1 || SR != 1 || MG, "SHIFT1 tiles run their second sub-round through sub1_shift");
+      if constexpr (SLO >= BL + 2 && SHIFT1) { for (int k = 0; k < 4; k++) base[k] = tile + ((R0 ^ ((R0 >> BL) & 3) ^ k) * C + c); }   // top digit: its low two bits (t & 3) are the second swizzle term
+      else if constexpr (SLO >= BL + 2) { base[0] = tile + ((R0 ^ ((R0 >> BL) & 3)) * C + c); base[1] = base[2] = base[3] = base[0]; }
+      else if constexpr (SLO == 0) { const int h3 = ((R0 >> BL) & 3) ^ (SHIFT1 ? ((R0 >> DG::slo(0)) & 3) : 0); for (int k = 0; k < 4; k++) base[k] = tile + ((R0 + (k ^ h3)) * C + c); }
+      else { for (int k = 0; k < 4; k++) base[k] = tile + ((R0 ^ k ^ (SHIFT1 ? ((R0 >> DG::slo(0)) & 3) : 0)) * C + c); }                // SLO == BL: the swizzle term is t & 3
       T x[1 << B];
 #pragma unroll
       for (int t = 0; t < (1 << B); t++) x[t] = base[t & 3][(SLO == 0 ? (t & ~3) : t * Q) * C];
@@ -539,6 +553,40 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     if constexpr (J + 1 < NJ) sub_items<SR, J + 1, MG>(tid, tile, w);
   }
 
+  // x * w_(2^(B1+BL))^(E * LO) for compile-time E, LO: a shift (2^96 == -1: exponents >= 96 negate)
+  template <int E, int LO> static MS_DEV T shift_tw(T v) {
+    constexpr int EXP = ((INV ? 153 : 39) * (64 >> (DG::bits(1) + BL)) * E * LO) % 192;
+    if constexpr (EXP == 0) return v;
+    else if constexpr (EXP >= 96) return A::sub((T)0, gl_mul_pow2<EXP - 96, A>(v));
+    else return gl_mul_pow2<EXP, A>(v);
+  }
+  template <int LO, int E = 1> static MS_DEV void shift_all(T (&x)[1 << DG::bits(1)]) {
+    constexpr int B = DG::bits(1);
+    x[bitrev(E, B)] = shift_tw<E, LO>(x[bitrev(E, B)]);
+    if constexpr (E + 1 < (1 << B)) shift_all<LO, E + 1>(x);
+  }
+  template <int LO = 0> static MS_DEV void shift_dispatch(int lo, T (&x)[1 << DG::bits(1)]) {   // `lo` is wave-uniform: scalar branches
+    if (lo == LO) { if constexpr (LO != 0) shift_all<LO>(x); return; }
+    if constexpr (LO + 1 < (1 << BL)) shift_dispatch<LO + 1>(lo, x);
+  }
+  // SHIFT1: the second sub-round with wave = lo (row bits [0, BL)), lane = (top digit hi, column c)
+  static MS_DEV void sub1_shift(int tid, T* tile) {
+    constexpr int B = DG::bits(1), Q = 1 << BL, SLO0 = DG::slo(0), HPJ = 64 >> LC, NJ = (1 << DG::bits(0)) / HPJ;
+    const int lo = msrt::wave_uniform(tid >> 6), lane = tid & 63, c = lane & (C - 1);
+#pragma unroll
+    for (int J = 0; J < NJ; J++) {
+      const int hi = (lane >> LC) + J * HPJ, R0 = (hi << SLO0) | lo;
+      T* base[4];
+      for (int k = 0; k < 4; k++) base[k] = tile + ((R0 ^ k ^ (hi & 3)) * C + c);   // element t at row R0 + t * Q: swizzle term (t & 3) ^ (hi & 3)
+      T x[1 << B];
+#pragma unroll
+      for (int t = 0; t < (1 << B); t++) x[t] = base[t & 3][t * Q * C];
+      dif_regs<A, INV, B>(x, (const T*)nullptr, K);    // Goldilocks butterflies need no table
+      shift_dispatch(lo, x);
+#pragma unroll
+      for (int e = 0; e < (1 << B); e++) base[e & 3][e * Q * C] = x[bitrev(e, B)];
+    }
+  }
   // ---- cooperative, persistent form: a workgroup walks tiles g = bx, bx + nbx, ... of the nbatch * tiles of the launch.
   // Fused tail: the last sub-round's lanes take VEC neighbouring columns of their 2^BL rows, so that what they hold after the
   // butterflies is exactly the 16-byte pieces of the store - no write-back of the last sub-round, no read-back for the store, one
@@ -592,6 +640,8 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     constexpr int NTB1 = NSUB == 3 ? (R >> B0) : 0;          // entries of tb1 (none with two sub-rounds: the second one is the last)
     static_assert(!MERGE || NTB1 + (1 << BL) * C <= R, "merged tables must fit the row-twiddle region");
     [[maybe_unused]] T* tb1 = twr; [[maybe_unused]] T* ts = twr + NTB1;
+    [[maybe_unused]] T* ts1 = twr + R / 2;     // SHIFT1 + MERGE: the store table [E1][E2][c] (fa | fb sit at the start of the region)
+    static_assert(!(MERGE && SHIFT1) || ((1 << DG::bits(1)) + (1 << BL) * C <= R / 2 && ((C << BL) << DG::bits(1)) <= R / 2), "store table must fit the row-twiddle region");
     if (!MERGE) for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
     size_t tl, by;
     locate(base_g + first, tiles, &tl, &by);
@@ -646,7 +696,23 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         }
       }
       msrt::wg_barrier();
-      if constexpr (MERGE) {   // the staged coefficients have been consumed: the region takes tb1 (read after the next barrier) and ts (read in the store phase)
+      if constexpr (MERGE && SHIFT1) {
+        // the staged coefficients have been consumed.  The second boundary is a shift, so the row-twiddle factor of ITS digit E1 moves into the store
+        // table: ts[E1][E2][c] = fa[E1] * fb[E2][c], fa[E1] = w_n^(X E1 2^B0), fb[E2][c] = w_n^(X E2 2^(B0+B1)) * w_n^(k_low c).  fa | fb (2^B1 + 2^BL C
+        // entries) are built here, the 2^(B1+BL) C products behind the next barrier (one per thread and tile); ts is read in the store phase.
+        const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
+        constexpr int NFA = 1 << DG::bits(1);
+        for (int idx = tid; idx < NFA + (1 << BL) * C; idx += TH) {
+          T v;
+          if (idx < NFA) v = tw_global(p, (X * (size_t)idx) << B0);
+          else {
+            const int j = idx - NFA, e = j >> LC, c = j & (C - 1);           // last digit x column
+            v = tw_global(p, (X * (size_t)e) << (K - BL));
+            if (k_low && c) v = A::mul_tw(v, tw_global(p, k_low * (size_t)c));
+          }
+          twr[idx] = v;
+        }
+      } else if constexpr (MERGE) {   // the staged coefficients have been consumed: the region takes tb1 (read after the next barrier) and ts (read in the store phase)
         const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
         for (int idx = tid; idx < NTB1 + (1 << BL) * C; idx += TH) {
           T v;
@@ -677,7 +743,20 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       }
       sub_items<0, 0, MERGE>(tid, tile, w);
       msrt::wg_barrier();
-      if constexpr (MERGE && NSUB == 3) sub_items<1, 0, true>(tid, tile, tb1); else sub_items<1, 0>(tid, tile, w);
+      if constexpr (SHIFT1) {
+        if constexpr (MERGE) {   // ts[E1][E2][c] = fa[E1] * fb[E2][c] (fa | fb complete behind the barrier above; read in the store phase, behind the next one)
+          if (row_tw) {
+            constexpr int NFA = 1 << DG::bits(1);
+            for (int idx = tid; idx < (NFA << BL) * C; idx += TH) {
+              const int e1 = idx >> (BL + LC), j = idx & (((1 << BL) * C) - 1);
+              T v = twr[NFA + j];
+              if (e1) v = A::mul_tw(v, twr[e1]);
+              ts1[idx] = v;
+            }
+          }
+        }
+        sub1_shift(tid, tile);
+      } else if constexpr (MERGE && NSUB == 3) sub_items<1, 0, true>(tid, tile, tb1); else sub_items<1, 0>(tid, tile, w);
       msrt::wg_barrier();
       T* dst = p.dst + by * p.dst_bstride;
       if constexpr (FUSE_TAIL) {
@@ -690,7 +769,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         V16 o[NJT][NE];
 #pragma unroll
         for (int J = 0; J < NJT; J++) {
-          const int itq = tid + J * TH, cq = (itq % LPR) * VEC, g = itq / LPR, R0 = g << BL, h3 = g & 3;
+          const int itq = tid + J * TH, cq = (itq % LPR) * VEC, g = itq / LPR, R0 = g << BL, h3 = (g & 3) ^ (SHIFT1 ? ((g >> DG::bits(1)) & 3) : 0);   // swizzle terms of row R0
 #pragma unroll
           for (int e = 0; e < NE; e++) o[J][e] = *reinterpret_cast<const V16*>(tile + (size_t)(R0 + (e & ~3) + ((e & 3) ^ h3)) * C + cq);
         }
@@ -710,7 +789,8 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #pragma unroll
             for (int e = 0; e < NE; e++) {
               T y = x[bitrev(e, BL)];
-              if constexpr (MERGE) { if (row_tw) y = A::mul_tw(y, ts[(e << LC) + cq + v]); }   // last digit's row factor x column twiddle
+              if constexpr (MERGE && SHIFT1) { if (row_tw) y = A::mul_tw(y, ts1[((((g & ((1 << B1_) - 1)) << BL) + e) << LC) + cq + v]); }   // row factors of the last two digits x column twiddle
+              else if constexpr (MERGE) { if (row_tw) y = A::mul_tw(y, ts[(e << LC) + cq + v]); }   // last digit's row factor x column twiddle
               else if (row_tw) y = A::mul_tw(y, twr[R0 + e]);
               if (col_tw && (cq + v)) y = A::mul_tw(y, gc[v]);
               if (do_scale) y = A::mul_tw(y, p.scale);

@@ -102,6 +102,7 @@ struct FiberBlock {
   }
 };
 inline void wg_barrier() { FiberBlock::active()->yield(); }
+inline int wave_uniform(int v) { return v; }
 // value of lane (lane ^ mask) of the caller's 64-lane wave; every thread of the workgroup must call it (like __shfl_xor under full exec)
 inline unsigned long long wave_shfl_xor(unsigned long long v, int mask) {
   FiberBlock* b = FiberBlock::active(); const int t = b->cur;
@@ -135,6 +136,7 @@ MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned
 
 #else  // ---------------------------------------------------------------- HIP (gfx950)
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #define MS_HD __host__ __device__ __forceinline__
 #define MS_DEV __device__ __forceinline__
 #define MS_RESTRICT __restrict__
@@ -142,7 +144,8 @@ namespace msrt {
 typedef ihipStream_t Stream;
 inline int malloc_dev(void** p, size_t n) { return (int)hipMalloc(p, n ? n : 1); }
 inline int free_dev(void* p) { return (int)hipFree(p); }
-inline int malloc_host(void** p, size_t n) { return (int)hipHostMalloc(p, n ? n : 1, hipHostMallocDefault); }
+// MS_PINNED_FLAGS (experiments): hipHostMalloc flags of the page-locked buffers, e.g. 0x80000000 = hipHostMallocNonCoherent
+inline int malloc_host(void** p, size_t n) { const char* e = getenv("MS_PINNED_FLAGS"); return (int)hipHostMalloc(p, n ? n : 1, e ? (unsigned)strtoul(e, nullptr, 0) : hipHostMallocDefault); }
 inline int free_host(void* p) { return (int)hipHostFree(p); }
 inline int h2d(void* d, const void* h, size_t n, Stream* s) { return (int)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); }
 inline int d2h(void* h, const void* d, size_t n, Stream* s) { return (int)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s); }
@@ -248,6 +251,8 @@ inline int launch_coop(Stream* s, unsigned gx, unsigned gy, int threads, size_t 
 
 MS_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 MS_DEV unsigned long long wave_shfl_xor(unsigned long long v, int mask) { return __shfl_xor(v, mask, 64); }
+// a value every lane of the wave holds alike, moved to a scalar register (so that branches on it are scalar branches)
+MS_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 MS_DEV void atomic_min_u64(unsigned long long* a, unsigned long long v) { atomicMin(a, v); }
 MS_DEV void atomic_max_u64(unsigned long long* a, unsigned long long v) { atomicMax(a, v); }
 MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { return atomicAdd(a, v); }

@@ -104,11 +104,30 @@ class ShardExchange:
         self.recv = torch.zeros(cap_bytes, dtype=torch.uint8, device=dev)
         self.calls = {0: 0, 1: 0, 2: 0, 3: 0}
         self.bytes = 0
+        self.slices = 0
         ctx.set_shard(group.rank, group.world, self.send.data_ptr(), self.recv.data_ptr(), cap_bytes, self._exchange if group.world > 1 else None)
 
     def _exchange(self, op, nbytes):
         try:
             W, d = self.g.world, self.dist
+            if op == 4:      # one slice of a sliced all-to-all: peer p's piece at offset + p * stride of both buffers
+                import ctypes as C
+                off, stride = C.c_size_t(0), C.c_size_t(0)
+                self.ctx.check(self.ctx.L.ms_shard_slice_layout(self.ctx.h, C.byref(off), C.byref(stride)))
+                off, stride = off.value, stride.value
+                self.slices += 1
+                self.bytes += nbytes * W
+                a = torch.stack([self.send[off + p * stride: off + p * stride + nbytes] for p in range(W)]).cpu().contiguous().view(-1)
+                b = torch.empty_like(a)
+                d.all_to_all_single(b, a)
+                b = b.view(W, nbytes).to(self.recv.device)
+                for p in range(W):
+                    self.recv[off + p * stride: off + p * stride + nbytes].copy_(b[p])
+                if off == 0:
+                    self.calls[0] += 1
+                if self.send.is_cuda:
+                    torch.cuda.synchronize()
+                return 0
             self.calls[op] += 1
             self.bytes += nbytes * (W if op == 0 else 1)
             if op == 0:      # all-to-all of W chunks

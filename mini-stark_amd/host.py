@@ -36,8 +36,11 @@ def _host():
             raise MsError(-6, f"{path} not found: run __graft_entry__.build()")
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)
         L.msh_stark_new.restype = C.c_void_p
-        for n in ("msh_proof_arthur", "msh_proof_evals", "msh_proof_fri_roots", "msh_proof_fri_blob", "msh_proof_challenges", "msh_proof_num_polys", "msh_proof_serialize"):
+        for n in ("msh_proof_arthur", "msh_proof_evals", "msh_proof_fri_roots", "msh_proof_fri_blob", "msh_proof_challenges", "msh_proof_num_polys", "msh_proof_serialize",
+                  "msh_prev_proof_arthur", "msh_prev_proof_fri_roots", "msh_prev_proof_fri_blob"):
             getattr(L, n).restype = C.c_size_t
+        L.msh_proof_blob_checksum.restype = C.c_uint64
+        L.msh_proof_blob_sample.restype = C.c_uint64
         _HOST = L
     return _HOST
 
@@ -65,7 +68,9 @@ class HostStark:
             pass
 
     def prove_raw(self, trace, trace_device_ptr=None, read_fri_proof=True):
-        """Runs the proof; returns the status code only (the bench loop)."""
+        """Runs the proof; returns the status code only (the bench loop).  read_fri_proof: False (the FRI proof stays in HBM), True (blocking
+        read-back), "async" (read-back on the copy stream; wait_proof() completes it), "into" (the query-phase kernels write the blob straight
+        into the slot's page-locked buffer: ms_fri_query_into)."""
         if not hasattr(trace, "_lin"):
             k = np.array([len(i) for _, i in trace.transitions], dtype=np.int32)
             sc = np.array([v for s, _ in trace.transitions for v in s], dtype=np.uint64)
@@ -75,7 +80,19 @@ class HostStark:
         host_ptr = None if trace_device_ptr is not None else trace.data.ctypes.data_as(C.POINTER(C.c_uint64))
         return self.H.msh_stark_prove(self.h, host_ptr, C.c_void_p(trace_device_ptr), C.c_size_t(trace.length), C.c_size_t(trace.width), C.c_int(len(k)),
                                       k.ctypes.data_as(C.POINTER(C.c_int)), sc.ctypes.data_as(C.POINTER(C.c_uint64)), ix.ctypes.data_as(C.POINTER(C.c_int)),
-                                      C.c_int(2 if read_fri_proof == "async" else (1 if read_fri_proof else 0)))
+                                      C.c_int({"async": 2, "into": 3}.get(read_fri_proof, 1 if read_fri_proof else 0)))
+
+    def blob_checksum(self, which=0):
+        """FNV-1a over the FRI blob of the last (0) / previous (1) proof, read in place from its page-locked slot (msh_proof_blob_checksum)."""
+        return int(self.H.msh_proof_blob_checksum(self.h, C.c_int(which)))
+
+    def blob_sample(self, which=0, stride_bytes=4096):
+        """FNV-1a over one word per `stride_bytes` of the blob (+ the last word): touches every page without reading all of it."""
+        return int(self.H.msh_proof_blob_sample(self.h, C.c_int(which), C.c_size_t(stride_bytes)))
+
+    def prev_fri_blob(self) -> bytes:
+        """The FRI blob of the proof BEFORE the last one: the mirror keeps two proof slots, so it stays whole while the next proof is computed."""
+        return self._bytes(self.H.msh_prev_proof_fri_blob)
 
     def wait_proof(self):
         """Completes an asynchronous read-back (read_fri_proof="async": the FRI proof travels into the mirror's page-locked buffer while

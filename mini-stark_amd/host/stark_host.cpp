@@ -424,14 +424,19 @@ size_t msh_prev_proof_fri_roots(const msh_stark* h, u8* out, size_t cap) { retur
 size_t msh_prev_proof_fri_blob(const msh_stark* h, u8* out, size_t cap) { return copy_out(h->s.prev.fri_blob.data(), h->s.prev.fri_blob.size(), out, cap); }
 // FNV-1a over the FRI blob of the last (which = 0) or the previous (which = 1) proof, read IN PLACE from the page-locked slot: what a consumer
 // that streams the proof out would touch (bench.py's I/O-inclusive leg reads every proof this way); 0 if there is none
-u64 msh_proof_blob_checksum(const msh_stark* h, int which) {
+static u64 blob_fnv(const msh_stark* h, int which, size_t stride_words) {
   if (which == 0) h->s.wait_proof();
   const PinnedBuf& b = which ? h->s.prev.fri_blob : h->s.proof.fri_blob;
   u64 x = 0xCBF29CE484222325ULL;
   const u64* w = (const u64*)b.data();
-  for (size_t i = 0; i < b.size() / 8; i++) { x ^= w[i]; x *= 0x100000001B3ULL; }
+  const size_t nw = b.size() / 8;
+  for (size_t i = 0; i < nw; i += stride_words) { x ^= w[i]; x *= 0x100000001B3ULL; }
+  if (nw) { x ^= w[nw - 1]; x *= 0x100000001B3ULL; }
   return b.size() ? x : 0;
 }
+u64 msh_proof_blob_checksum(const msh_stark* h, int which) { return blob_fnv(h, which, 1); }
+// the same over one word per `stride_bytes` (and the last word): touches every page of the blob without the cost of reading 64 MiB
+u64 msh_proof_blob_sample(const msh_stark* h, int which, size_t stride_bytes) { return blob_fnv(h, which, stride_bytes >= 8 ? stride_bytes / 8 : 1); }
 static int set_why(char* why, size_t why_cap, const char* msg, int rc);
 // Stark::verify (src/starks.rs:171-235) of a proof given by its parts; `constrains` = the c constraint polynomials in coefficient
 // form ([c][N] canonical u64: what trace.derive_constrains() hands the reference's verifier).  1 accepted, 0 rejected, < 0 malformed;

@@ -67,7 +67,7 @@ def case_merkle(mk, field, leaf_num, ext, lpn, ic, special=False):
         assert root == oroot
 
 
-def drive(sess, field, trace, blowup, nq_fri, seed, rounds=None, q_ood=2, read_big=True, base_field_z_rounds=()):
+def drive(sess, field, trace, blowup, nq_fri, seed, rounds=None, q_ood=2, read_big=True, base_field_z_rounds=(), fixed_betas=None):
     """Runs one full prove on `sess` (oracle Session or mini_stark_amd Context) with challenges
     drawn from SplitMix64(seed); returns the list of stage outputs."""
     p, e = MODULUS[field], EXT[field]
@@ -117,7 +117,7 @@ def drive(sess, field, trace, blowup, nq_fri, seed, rounds=None, q_ood=2, read_b
         if read_big:
             out.append((f"round_poly{i}", sess.fri_round_poly(i).tolist()))
             out.append((f"round_cw{i}", sess.fri_round_codeword(i).tolist()))
-    betas = [rng.next() for _ in range(nq_fri)] + [3, 2 * N * blowup]
+    betas = [rng.next() for _ in range(nq_fri)] + list([3, 2 * N * blowup] if fixed_betas is None else fixed_betas)
     rc, proof = sess.fri_query(betas)
     assert rc == 0
     out.append(("fri_proof", proof))

@@ -44,6 +44,6 @@ for (ka, va), (kb, vb) in zip(got, want):
 assert ctx.L.ms_lde_read(ctx.h, None) != 0
 grp.barrier()
 if grp.rank == 0:
-    print(json.dumps({"world": grp.world, "calls": xchg.calls, "bytes": xchg.bytes, "stages": len(got)}), flush=True)
+    print(json.dumps({"world": grp.world, "calls": xchg.calls, "bytes": xchg.bytes, "stages": len(got), "slices": xchg.slices}), flush=True)
 xchg.close()
 grp.close()

@@ -59,3 +59,77 @@ def test_rust_ffi_block_matches_header():
     for stage in ("ms_trace_commit", "ms_interpolate", "ms_polys_lincomb", "ms_lde_commit", "ms_mix", "ms_eval_ext", "ms_fri_begin", "ms_fri_deep",
                   "ms_fri_fold_commit", "ms_fri_query", "ms_fri_proof_read"):
         assert stage in used, stage
+
+
+def _c_arity():
+    """name -> number of parameters, from the C declarations of include/ministark.h"""
+    text = open(os.path.join(ROOT, "include", "ministark.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(ms_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else _split_top(args)
+    return out
+
+
+def _split_top(s):
+    depth, n = 0, 1
+    for ch in s:
+        depth += ch in "([{<"
+        depth -= ch in ")]}>"
+        if ch == "," and depth == 0:
+            n += 1
+    return n
+
+
+def _calls(text, prefix):
+    """(name, number of top-level arguments) of every call `prefix...(` in Rust source `text`"""
+    out = []
+    for m in re.finditer(r"\b(%s[A-Za-z0-9_]*)\s*\(" % prefix, text):
+        i, depth = m.end(), 1
+        while depth and i < len(text):
+            depth += text[i] in "([{"
+            depth -= text[i] in ")]}"
+            i += 1
+        args = text[m.end():i - 1].strip()
+        out.append((m.group(1), 0 if not args else _split_top(args)))
+    return out
+
+
+def test_rust_shim_files_call_the_abi_with_the_right_arity():
+    """SURVEY 8(f) rank 4 as FILES: tree.rs (`impl Tree for GpuMerkleTree`), prove.rs (`Stark::prove_gpu`), fri_proof.rs
+    (`FriProof::from_msfp`) exist without `unimplemented!()`; every `ms_*` call of the crate names a function of include/ministark.h with the
+    header's number of arguments (declarations in ffi.rs and calls in lib.rs alike); every `gpu.<stage>()` call of tree.rs / prove.rs is a
+    method lib.rs defines, with the right number of arguments.  (Not compiled here: no cargo; the C twin of from_msfp, msh_fri_proof_parse,
+    is compiled and tested in tests/test_host_mirror.py.)"""
+    src = os.path.join(ROOT, "examples", "rust_shim", "src")
+    files = {n: open(os.path.join(src, n)).read() for n in ("ffi.rs", "lib.rs", "tree.rs", "prove.rs", "fri_proof.rs", "convert.rs")}
+    code = {n: re.sub(r"//[^\n]*", "", t) for n, t in files.items()}      # comments out
+    for n in ("tree.rs", "prove.rs", "fri_proof.rs", "lib.rs"):
+        assert "unimplemented!" not in code[n] and "todo!" not in code[n], n
+    assert "impl<F: FftField> Tree for GpuMerkleTree<Sha256, F>" in code["tree.rs"]
+    assert "pub fn prove_gpu" in code["prove.rs"] and "pub fn from_msfp" in code["fri_proof.rs"]
+    arity = _c_arity()
+    # declarations: `pub fn ms_x(a: T, b: U) -> c_int;`
+    for name, n in _calls(re.sub(r"pub fn ", "", code["ffi.rs"].split('extern "C" {', 1)[1]), "ms_"):
+        assert arity.get(name) == n, (name, n, arity.get(name))
+    # calls in the safe wrapper
+    calls = _calls(code["lib.rs"], "ms_")
+    assert len(calls) >= 15
+    for name, n in calls:
+        assert name in arity and arity[name] == n, ("lib.rs", name, n, arity.get(name))
+    # gpu.<method>(...) in tree.rs / prove.rs against the methods of `impl Gpu`
+    methods = {}
+    for m in re.finditer(r"pub fn ([a-z_0-9]+)\s*\(\s*&(?:mut )?self\s*,?([^)]*)\)", code["lib.rs"]):
+        rest = m.group(2).strip()
+        methods[m.group(1)] = 0 if not rest else _split_top(rest)
+    used = []
+    for n in ("tree.rs", "prove.rs"):
+        used += [(n,) + c for c in _calls(code[n], r"gpu\.")]
+    assert len(used) >= 10
+    for fname, call, n in used:
+        meth = call.split(".", 1)[1]
+        assert meth in methods and methods[meth] == n, (fname, call, n, methods.get(meth))
+    for stage in ("trace_commit", "interpolate", "polys_lincomb", "lde_commit", "mix", "eval_ext", "fri_begin", "fri_deep", "fri_fold_commit", "fri_query"):
+        assert any(c[1] == "gpu." + stage for c in used if c[0] == "prove.rs"), stage
+    assert any(c[1] == "gpu.merkle_commit" for c in used if c[0] == "tree.rs")

@@ -255,6 +255,42 @@ def test_async_proof_readback_matches_blocking(emu, field):
     ctx.close()
 
 
+@pytest.mark.parametrize("field", [0, 1])
+def test_proof_written_into_pinned_memory_and_two_proof_slots(emu, field):
+    check_into_and_slots(ms.Context(field, lib_path=emu), 63)
+
+
+def check_into_and_slots(ctx, steps):
+    """read_fri_proof="into" (ms_fri_query_into: the query-phase kernels write the MSFP blob straight into the mirror's page-locked slot, no
+    read-back copy) delivers the bytes of the blocking read-back; and the mirror's TWO proof slots keep proof k whole - transcript,
+    roots and FRI blob - while proof k + 1 is computed, in every read-back mode (in async mode the next prove starts before the bytes arrived)."""
+    blowup = 8
+    tts = [fibonacci_air(ctx, steps, secret_b=b) for b in (2, 5, 9, 11)]
+    hs = HostStark(ctx, 20, blowup, steps, tts[0].constrain_number())
+    want = [hs.prove(tt).fri_proof.blob for tt in tts]
+    assert len(set(want)) == 4
+    for mode in ("into", "async", True):
+        sums = []
+        for k, tt in enumerate(tts):
+            ctx.check(hs.prove_raw(tt, read_fri_proof=mode))
+            if k:   # proof k - 1 is still there, untouched by proof k (which may still be arriving: nothing has waited for it yet)
+                assert hs.prev_fri_blob() == want[k - 1], (mode, k)
+                assert hs.blob_checksum(1) == sums[-1]
+            sums.append(hs.blob_checksum(0))
+            assert hs.last_proof().fri_proof.blob == want[k], (mode, k)
+        assert len(set(sums)) == 4
+    # the library refuses a read-back of a proof it wrote into the caller's buffer, and a buffer that is too small
+    import ctypes as C
+    ctx.check(hs.prove_raw(tts[0], read_fri_proof="into"))
+    buf = (C.c_uint8 * 16)()
+    assert ctx.L.ms_fri_proof_read(ctx.h, buf) == ms.ERR_STATE
+    n = C.c_size_t(0)
+    betas = (C.c_uint64 * hs.fri_queries)(*([3] * hs.fri_queries))
+    assert ctx.L.ms_fri_query_into(ctx.h, betas, C.c_int(hs.fri_queries), None, C.c_size_t(0), C.byref(n)) == 0 and n.value == len(want[0])
+    assert ctx.L.ms_fri_query_into(ctx.h, betas, C.c_int(hs.fri_queries), buf, C.c_size_t(16), C.byref(n)) == -5
+    ctx.close()
+
+
 @pytest.mark.parametrize("field,steps", [(0, 63), (1, 31)])
 def test_mssp_crafted_length_fields_are_refused(emu, field, steps):
     """a single wrapping sum used to accept arthur_len = 2^64 - 1000 with fri_blob_len enlarged to compensate, and the
