@@ -366,6 +366,10 @@ template <> struct Affix<4> {
 // (row-major trace: width=1,row_stride=1; column-major LDE: width=c,col_stride=L;
 //  FRI codeword: width=1, limb_stride=D).
 // One thread owns one digest and walks the base limbs of its group: affix, decimal, affix, drain.
+// A VIRTUAL column of the committed matrix (r03): column `col` = sum_t s[t] * column src[t] of the same row, computed while the row is hashed - the linear
+// LDE columns (transition polynomials that ms_polys_lincomb defined, starks.rs:80-91 by linearity) are only ever hashed, so they need not exist in HBM.
+constexpr int LIN_MAXT = 4;
+struct LinColSpec { u32 n /* 0: a stored column */; u32 src[LIN_MAXT]; u64 s[LIN_MAXT]; };
 template <class F, int E, bool LAZY = false> struct LeafHashKernel {
   typedef typename F::T T;
   static constexpr int THREADS = msmerkle::THREADS;
@@ -378,6 +382,7 @@ template <class F, int E, bool LAZY = false> struct LeafHashKernel {
     // run_len != 0: the launch hashes `ngroups` groups that are RUNS of run_len consecutive groups, run_stride apart, from g_first on (one slice of
     // every peer's chunk of a sharded commitment: its digests can travel while the next slice is hashed)
     size_t g_first; u32 run_len, run_stride;
+    const LinColSpec* lin;   // per column of the matrix (width entries), or nullptr: no virtual columns
   };
   static constexpr int MAX_BYTES = F::MAX_DIGITS + Affix<E>::MAX_BYTES;  // appended between two drains
   static constexpr int MAXW = (3 + MAX_BYTES + 3) / 4 + 1;               // words one iteration can touch past the write position
@@ -398,7 +403,18 @@ template <class F, int E, bool LAZY = false> struct LeafHashKernel {
     for (u32 j = 0; LAZY || j <= nlimbs; j++) {
       if (j < nlimbs) {
         const u32 k = j & (u32)(E - 1);
-        const T v = p.base[(size_t)col * p.col_stride + row * p.row_stride + (size_t)k * p.limb_stride];
+        const T* rowp = p.base + row * p.row_stride + (size_t)k * p.limb_stride;
+        T v;
+        if (p.lin && p.lin[col].n) {   // (col is the same on every lane when a group is one row: scalar loads of the spec)
+          const LinColSpec& lc = p.lin[col];
+          v = 0;
+          for (u32 t = 0; t < lc.n; t++) {   // scalars 1 and -1 (every Fibonacci transition has them) cost an add / sub, not a multiplication
+            const T x = rowp[(size_t)lc.src[t] * p.col_stride];
+            if (lc.s[t] == 1) v = F::add(v, x);
+            else if (lc.s[t] == F::P - 1) v = F::sub(v, x);
+            else v = F::add(v, F::mul(x, F::from_u64(lc.s[t])));
+          }
+        } else v = rowp[(size_t)col * p.col_stride];
         Affix<E>::before(s, k);
         put_dec<F>(s, v, p.zero_as_empty);
         Affix<E>::after(s, k);
@@ -461,7 +477,8 @@ struct PadOnlyBlockKernel {
 // nlevels > 1 the grid must be a single workgroup (fused tree top).
 // IC > 0: inner_children fixed at compile time (IC = 2 is the prover's tree, starks.rs:290-301: the padding block's
 // message schedule then folds to literals); IC = 0: taken from Params.
-struct InnerHashParams { u32* nodes; size_t child_off, nchildren; u32 ic; u32 nlevels; u32* host_root; /* optional: page-locked host memory that also receives the root (nparents == 1) */ };
+struct InnerHashParams { u32* nodes; size_t child_off, nchildren; u32 ic; u32 nlevels; u32* host_root; /* optional: page-locked host memory that also receives the root (nparents == 1) */
+                         unsigned long long* aux_src; unsigned long long* aux_dst; /* optional: one more 8-byte result (the round polynomial's trimmed length) forwarded to page-locked host memory by the same thread */ };
 template <int IC> struct InnerHashKernelT {
   static constexpr int THREADS = msmerkle::THREADS;
   typedef InnerHashParams Params;
@@ -501,7 +518,10 @@ template <int IC> struct InnerHashKernelT {
       o0.x = bswap32(h.st[0]); o0.y = bswap32(h.st[1]); o0.z = bswap32(h.st[2]); o0.w = bswap32(h.st[3]);
       o1.x = bswap32(h.st[4]); o1.y = bswap32(h.st[5]); o1.z = bswap32(h.st[6]); o1.w = bswap32(h.st[7]);
       out[0] = o0; out[1] = o1;
-      if (p.host_root && nparents == 1) { uint4_t* hr = reinterpret_cast<uint4_t*>(p.host_root); hr[0] = o0; hr[1] = o1; }   // saves the caller a 32-byte copy launch
+      if (p.host_root && nparents == 1) {   // saves the caller the copy launches (32-byte root, 8-byte degree word) in front of its stream synchronisation
+        uint4_t* hr = reinterpret_cast<uint4_t*>(p.host_root); hr[0] = o0; hr[1] = o1;
+        if (p.aux_src) { *p.aux_dst = *p.aux_src; *p.aux_src = 0; }   // ... and the device word is zero again for the next round's scan
+      }
       if (stride == 0) break;
     }
   }

@@ -656,7 +656,7 @@ template <class F> struct Ctx : CtxBase {
   // leaf-group digests of `ngroups` groups into `out`: LeafHashKernel + the compacted pad-only blocks it deferred
   template <int EL>
   int leaf_hash(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, size_t lpn, size_t ngroups, u32* out,
-                size_t g_first = 0, u32 run_len = 0, u32 run_stride = 0) {
+                size_t g_first = 0, u32 run_len = 0, u32 run_stride = 0, const msmerkle::LinColSpec* lin = nullptr) {
     if (ngroups >> 32) return fail(MS_ERR_SHAPE, "more than 2^32 leaf groups");
     // deferred pad-only blocks: OVF_LISTS lists, list l fed by the workgroups bx = l (mod OVF_LISTS); capacity = all their threads
     const size_t nwg = grid1(ngroups, msmerkle::THREADS), lists = msmerkle::OVF_LISTS;
@@ -668,14 +668,14 @@ template <class F> struct Ctx : CtxBase {
     lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
     lp.width = width; lp.lpn = (u32)lpn; lp.zero_as_empty = zae; lp.ngroups = ngroups; lp.nodes = out;
     lp.ovf_count = reinterpret_cast<u32*>(counters); lp.ovf = d_ovf.as<u32>(); lp.ovf_cap = (u32)cap;
-    lp.g_first = g_first; lp.run_len = run_len; lp.run_stride = run_stride;
+    lp.g_first = g_first; lp.run_len = run_len; lp.run_stride = run_stride; lp.lin = lin;
     next_bytes = (double)ngroups * (lpn * EL * sizeof(T) + 32);
     if (lpn * EL >= (size_t)leaf_lazy_min) {  // long messages (wide rows): the two-block buffer that compresses wave-synchronously
       typedef msmerkle::LeafHashKernel<F, EL, true> LK;
       typename LK::Params ll;
       ll.base = lp.base; ll.col_stride = lp.col_stride; ll.row_stride = lp.row_stride; ll.limb_stride = lp.limb_stride; ll.width = lp.width; ll.lpn = lp.lpn;
       ll.zero_as_empty = lp.zero_as_empty; ll.ngroups = lp.ngroups; ll.nodes = lp.nodes; ll.ovf_count = lp.ovf_count; ll.ovf = lp.ovf; ll.ovf_cap = lp.ovf_cap;
-      ll.g_first = g_first; ll.run_len = run_len; ll.run_stride = run_stride;
+      ll.g_first = g_first; ll.run_len = run_len; ll.run_stride = run_stride; ll.lin = lin;
       CK(run<LK>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, LK::lds_bytes(), ll));
     } else
     CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
@@ -685,10 +685,10 @@ template <class F> struct Ctx : CtxBase {
     return 0;
   }
   template <int EL>
-  int tree_build(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, const TreeShape& ts, DevBuf& nodes) {
+  int tree_build(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, const TreeShape& ts, DevBuf& nodes, const msmerkle::LinColSpec* lin = nullptr) {
     if (nodes.ensure(ts.nodes * 32)) return fail(MS_ERR_NOMEM, "merkle nodes");
     const size_t ngroups = ts.leaf_num / ts.lpn;
-    RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, ngroups, nodes.as<u32>())));
+    RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, ngroups, nodes.as<u32>(), 0, 0, 0, lin)));
     RQ(inner_levels(nodes.as<u32>(), ngroups, ts.ic));
     return 0;
   }
@@ -697,14 +697,18 @@ template <class F> struct Ctx : CtxBase {
   // (root_on_host: read_root / read_degree_and_root then need no copy launch, only the stream synchronisation they do anyway)
   u32* host_root() const { return reinterpret_cast<u32*>(reinterpret_cast<u8*>(pinned) + 256); }
   bool root_on_host = false;
+  unsigned long long* pending_aux = nullptr; bool aux_on_host = false;   // a device word the tree's final launch forwards to pinned[0] (the degree result)
   int inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_levels = true) {
     size_t child_off = 0;
     if (final_levels) root_on_host = false;
     while (nchildren > 1) {
       msmerkle::InnerHashKernel::Params ip;
-      ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic; ip.host_root = nullptr;
+      ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic; ip.host_root = nullptr; ip.aux_src = nullptr; ip.aux_dst = nullptr;
       const size_t nparents = nchildren / ic;
-      if (final_levels && (nparents == 1 || nparents <= (size_t)tree_top_parents)) { ip.host_root = host_root(); root_on_host = true; }
+      if (final_levels && (nparents == 1 || nparents <= (size_t)tree_top_parents)) {
+        ip.host_root = host_root(); root_on_host = true;
+        if (pending_aux) { ip.aux_src = pending_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
+      }
       if (nparents <= (size_t)tree_top_parents) {  // fused tree top: one workgroup walks the remaining levels
         u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ic) nl++;
         ip.nlevels = nl;
@@ -724,7 +728,7 @@ template <class F> struct Ctx : CtxBase {
   // Sharded MerkleTree::new over a binary tree of M = leaf_num/lpn leaf groups, of which this rank hashes the groups
   // j = rank + W*i found at local group index i of the view (base, strides): digest all-to-all, subtree, root all-gather, top.
   template <int EL>
-  int tree_build_sharded(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, TreeShape& ts, DevBuf& nodes) {
+  int tree_build_sharded(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, TreeShape& ts, DevBuf& nodes, const msmerkle::LinColSpec* lin = nullptr) {
     const size_t W = (size_t)sh_world, M = ts.leaf_num / ts.lpn, Mloc = M / W, per = Mloc / W;
     if (ts.ic != 2 || per == 0) return fail(MS_ERR_STATE, "sharded tree needs a binary tree with at least world^2 leaf groups");
     if (Mloc * 32 > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small for the sharded commitment (need 32 * leaf groups / world bytes)");
@@ -735,12 +739,12 @@ template <class F> struct Ctx : CtxBase {
     // MS_SHARD_SLICE_MIN (1024 groups per peer and slice; below that the commitment goes out in one piece).
     const size_t S = (shard_slices > 1 && per % (size_t)shard_slices == 0 && per / (size_t)shard_slices >= shard_slice_min) ? (size_t)shard_slices : 1;
     if (S == 1) {
-      RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, reinterpret_cast<u32*>(xs))));
+      RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, reinterpret_cast<u32*>(xs), 0, 0, 0, lin)));
       RQ(exchange(MS_XCHG_ALL_TO_ALL, per * 32));
     } else {
       const size_t q = per / S;
       for (size_t sl = 0; sl < S; sl++) {
-        RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, W * q, reinterpret_cast<u32*>(xs), sl * q, (u32)q, (u32)per)));
+        RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, W * q, reinterpret_cast<u32*>(xs), sl * q, (u32)q, (u32)per, lin)));
         RQ(exchange_slice(sl * q * 32, per * 32, q * 32, (int)sl, (int)S));
       }
     }
@@ -809,6 +813,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_V2_MIN")) { int v = atoi(e); if (v >= 12 && v <= 32) ntt_v2_min = v; }
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
     if (const char* e = getenv("MS_LDE_MULTI")) lde_multi = atoi(e);
+    if (const char* e = getenv("MS_LDE_VIRTUAL")) lde_virtual = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
     if (const char* e = getenv("MS_LEAF_LAZY_MIN")) leaf_lazy_min = atoi(e);
     if (const char* e = getenv("MS_TREE_TOP")) { int v = atoi(e); if (v >= 1 && v <= 65536) tree_top_parents = v; }
@@ -836,7 +841,7 @@ template <class F> struct Ctx : CtxBase {
     if (ev_copy) msrt::event_destroy(ev_copy);
     if (copy_stream) msrt::stream_destroy(copy_stream);
     for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
-    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero};
+    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero, &d_lin};
     for (DevBuf* b : bufs) b->release();
     if (pinned) msrt::free_host(pinned);
     if (own_stream) msrt::stream_destroy(own_stream);
@@ -1015,9 +1020,46 @@ template <class F> struct Ctx : CtxBase {
       RQ(ntt_run(ctz64(L_), false, d_coef.as<T>() + i * N, N, N, d_lde.as<T>() + i * L_, L_, j - i));
       i = j;
     }
-    if (lde_linear) RQ(lincomb_linear_columns(d_lde.as<T>(), L_, L_));
+    if (lde_linear) RQ(finish_linear_columns(L_, L_));
     return 0;
   }
+  // The linear LDE columns: VIRTUAL when every one of them is a combination of at most LIN_MAXT stored (transformed) columns - the leaf-hash kernel
+  // then evaluates them row by row while it hashes (they are never read again: the query phase opens FRI codewords only) and ms_lde_read materialises
+  // them on demand; otherwise written out by the lincomb kernels.  MS_LDE_VIRTUAL: -1 (default) for AIRs of >= 16 polynomials, 0 never, 1 always.
+  // Measured r03: wide AIR (64 linear columns of 2^25 rows) LDE commit 105.5 -> 103.6 ms - the 20 ms of lincomb launches go away, but the leaf kernel reads
+  // its source columns again (out of L2 by then) and multiplies; Fibonacci AIR with 8 proofs in flight 239 -> 233 proofs/s (the prover is bound by its VALU
+  // instruction count, and the leaf kernel's grew): so narrow AIRs keep the lincomb kernels.
+  int lde_virtual = -1; bool lde_cols_virtual = false; size_t lde_col_stride = 0, lde_col_len = 0;
+  DevBuf d_lin;
+  int finish_linear_columns(size_t stride, size_t n) {
+    const size_t c = (size_t)npolys;
+    lde_cols_virtual = false; lde_col_stride = stride; lde_col_len = n;
+    bool any = false, simple = lde_virtual < 0 ? c >= 16 : lde_virtual != 0;
+    for (size_t i = 0; i < c; i++) {
+      const Lin& li = poly_lin[i];
+      if (li.idx.empty()) continue;
+      any = true;
+      if (li.idx.size() > (size_t)msmerkle::LIN_MAXT) simple = false;
+      for (int ix : li.idx) if (ix < 0 || (size_t)ix >= c || !poly_lin[ix].idx.empty()) simple = false;
+    }
+    if (!any) return 0;
+    if (!simple) return lincomb_linear_columns(d_lde.as<T>(), stride, n);
+    std::vector<msmerkle::LinColSpec> spec(c);
+    for (size_t i = 0; i < c; i++) {
+      memset(&spec[i], 0, sizeof spec[i]);
+      const Lin& li = poly_lin[i];
+      spec[i].n = (u32)li.idx.size();
+      for (size_t t = 0; t < li.idx.size(); t++) { spec[i].src[t] = (u32)li.idx[t]; spec[i].s[t] = li.s[t] % F::P; }
+    }
+    if (d_lin.ensure(c * sizeof(msmerkle::LinColSpec))) return fail(MS_ERR_NOMEM, "virtual column table");
+    if (c * sizeof(msmerkle::LinColSpec) > pinned_cap - 8192) return lincomb_linear_columns(d_lde.as<T>(), stride, n);
+    // staged through page-locked memory behind the small results: the previous proof's copy out of it completed before that proof's lde_commit returned
+    memcpy(reinterpret_cast<u8*>(pinned) + 8192, spec.data(), c * sizeof(msmerkle::LinColSpec));
+    CK(msrt::h2d(d_lin.p, reinterpret_cast<u8*>(pinned) + 8192, c * sizeof(msmerkle::LinColSpec), stream));
+    lde_cols_virtual = true;
+    return 0;
+  }
+  const msmerkle::LinColSpec* lde_lin() const { return lde_cols_virtual ? d_lin.as<msmerkle::LinColSpec>() : nullptr; }
   // Evaluations of `batch` polynomials (ncoef coefficients each) on this rank's share of the size-2^log_D domain shift*<w_D>:
   // the rows g*(rank + W*i) + t (t < g, i < m = D/(g*W)) — g cosets of <w_m> — land at dst[b*dst_bstride + t*m + i].
   int coset_eval(const T* coef, size_t coef_bstride, size_t ncoef, int log_D, T shift, size_t g, T* dst, size_t dst_bstride, size_t batch) {
@@ -1049,7 +1091,7 @@ template <class F> struct Ctx : CtxBase {
       RQ(coset_eval(d_polys.as<T>() + i * N, N, N, ctz64(L_), F::from_u64(shift), 1, d_lde.as<T>() + i * m, m, j - i));
       i = j;
     }
-    if (lde_linear) RQ(lincomb_linear_columns(d_lde.as<T>(), m, m));
+    if (lde_linear) RQ(finish_linear_columns(m, m));
     return 0;
   }
   int lde_commit(size_t blowup_, u64 shift, size_t lpn, u8* root) override {
@@ -1063,10 +1105,10 @@ template <class F> struct Ctx : CtxBase {
     L = L_; blowup = blowup_; lde_c = c;
     if (lpn == c && shardable(L_)) {  // one LDE row per leaf group: rank k evaluates and hashes the rows k (mod world)
       RQ(lde_compute_sharded(blowup_, shift));
-      RQ((tree_build_sharded<1>(d_lde.as<T>(), L / (size_t)sh_world, 1, 0, (u32)c, ts, d_lde_nodes)));
+      RQ((tree_build_sharded<1>(d_lde.as<T>(), L / (size_t)sh_world, 1, 0, (u32)c, ts, d_lde_nodes, lde_lin())));
     } else {
       RQ(lde_compute(blowup_, shift));
-      RQ((tree_build<1>(d_lde.as<T>(), L, 1, 0, (u32)c, ts, d_lde_nodes)));
+      RQ((tree_build<1>(d_lde.as<T>(), L, 1, 0, (u32)c, ts, d_lde_nodes, lde_lin())));
     }
     lde_ts = ts;
     RQ(read_root(d_lde_nodes, ts, root));
@@ -1098,6 +1140,7 @@ template <class F> struct Ctx : CtxBase {
   int lde_read(u64* out) override {
     if (!have_lde || !out) return fail(MS_ERR_STATE, "lde_read");
     if (lde_ts.sharded) return fail(MS_ERR_STATE, "lde_read: the LDE of a sharded proof is distributed over the ranks");
+    if (lde_cols_virtual) { RQ(lincomb_linear_columns(d_lde.as<T>(), lde_col_stride, lde_col_len)); lde_cols_virtual = false; }   // the virtual columns, written out on demand
     const size_t tot = L * lde_c;
     if (d_io.ensure(tot * 8)) return fail(MS_ERR_NOMEM, "io");
     typename mspoly::TransposeOutKernel<F>::Params p{d_lde.as<T>(), d_io.as<u64>(), L, lde_c, L};
@@ -1235,7 +1278,8 @@ template <class F> struct Ctx : CtxBase {
     RQ((tree_build<E>(r->cw.template as<T>(), 0, 1, r->D, 1, r->ts, r->nodes)));                                       // fri.rs:351
     return 0;
   }
-  int read_degree_and_root(const T* poly, size_t limb_stride, size_t n, Round* r, size_t* ncoef, u8* root) {
+  // trimmed length of a round polynomial (DegreeKernel) into a zeroed device word
+  int degree_launch(const T* poly, size_t limb_stride, size_t n, unsigned long long** dres_out) {
     void* zr;
     RQ(zero_alloc(8, &zr));
     unsigned long long* dres = reinterpret_cast<unsigned long long*>(zr);
@@ -1243,6 +1287,12 @@ template <class F> struct Ctx : CtxBase {
       typename mspoly::DegreeKernel<F, E>::Params dp{poly, limb_stride, n, dres};
       CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
     }
+    *dres_out = dres;
+    return 0;
+  }
+  int read_degree_and_root(const T* poly, size_t limb_stride, size_t n, Round* r, size_t* ncoef, u8* root) {
+    unsigned long long* dres;
+    RQ(degree_launch(poly, limb_stride, n, &dres));
     const bool on_host = r && root_on_host;   // r's tree is the one built last (round_commit just before)
     CK(msrt::d2h(pinned, dres, 8, stream));
     if (r && !on_host) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, r->nodes.template as<u8>() + (r->ts.local_nodes - 1) * 32, 32, stream));
@@ -1372,10 +1422,23 @@ template <class F> struct Ctx : CtxBase {
       RQ(suffix_horner(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), nr->cap, 0, 1, nullptr));
       nq_coef = m - 1;
     }
+    // the degree scan runs BEFORE the commitment and the tree's final launch forwards its 8-byte result, with the root, into page-locked host memory:
+    // no copy launch in front of the round's one stream synchronisation (r03; the trace showed a 4 us copyBuffer kernel + its launch gap per round)
+    // (the word lives in d_deg, zeroed once: the forwarding thread clears it again - the pool of zero_alloc may be wiped while the tree is being built)
+    if (!d_deg.p) { if (d_deg.ensure(256)) return fail(MS_ERR_NOMEM, "degree word"); CK(msrt::memset_dev(d_deg.p, 0, 256, stream)); }
+    unsigned long long* dres = d_deg.as<unsigned long long>();
+    if (nq_coef) {
+      typename mspoly::DegreeKernel<F, E>::Params dp{nr->poly.template as<T>(), nr->cap, nq_coef, dres};
+      CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(nq_coef, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
+    }
+    pending_aux = dres; aux_on_host = false;
     RQ(round_commit(nr, nq_coef, E, pr, &a));
-    size_t nc;
-    RQ(read_degree_and_root(nr->poly.template as<T>(), nr->cap, nq_coef, nr, &nc, root));
-    nr->ncoef = nc;
+    pending_aux = nullptr;
+    if (!aux_on_host) { CK(msrt::d2h(pinned, dres, 8, stream)); CK(msrt::memset_dev(dres, 0, 8, stream)); }
+    if (!root_on_host) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, nr->nodes.template as<u8>() + (nr->ts.local_nodes - 1) * 32, 32, stream));
+    CK(msrt::sync(stream));
+    nr->ncoef = (size_t)(*reinterpret_cast<unsigned long long*>(pinned));
+    memcpy(root, root_on_host ? reinterpret_cast<const u8*>(host_root()) : reinterpret_cast<const u8*>(pinned) + 64, 32);
     nrounds_done++; have_deep = false;
     return MS_OK;
   }

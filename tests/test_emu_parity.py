@@ -217,3 +217,25 @@ def test_arith_selftest(mk, field):
     """ADVICE r2 / VERDICT r2 #3: the NTT tiles' arithmetic class op by op against big integers (GPU: the exec-masked asm class GLM itself;
     emulation: the formulas it falls back to - the entry point's plumbing)."""
     pc.case_arith_selftest(mk, field, nrand=1 << 12)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_many_proofs_on_one_context_stay_identical(mk, field):
+    """The same proof 80 times on ONE context: the pool of zeroed device words (counters of the deferred-block lists, degree results) wraps and is
+    wiped several times on the way - a result that lived in it across a wipe would change (r03: the degree word forwarded by the tree's last launch)."""
+    from common import fibonacci_trace
+    ctx = mk(field, fresh=True)
+    tr = fibonacci_trace(field, 32)
+    first = pc.drive(ctx, field, tr, 8, 1, seed=3, read_big=False)
+    for _ in range(80):
+        assert pc.drive(ctx, field, tr, 8, 1, seed=3, read_big=False) == first
+
+
+@pytest.mark.parametrize("field,virtual", [(0, "1"), (1, "1"), (0, "0")])
+def test_virtual_linear_lde_columns(mk, monkeypatch, field, virtual):
+    """r03: the linear LDE columns evaluated row by row inside the leaf-hash kernel (MS_LDE_VIRTUAL; default: AIRs of >= 16 polynomials) instead of being
+    written out by the lincomb kernels - same LDE root, same LDE matrix on ms_lde_read (materialised on demand), same proof, forced on and off."""
+    monkeypatch.setenv("MS_LDE_VIRTUAL", virtual)
+    fresh = lambda f, fresh=False: mk(f, fresh=True)
+    pc.case_prove(fresh, field, 8, 8)
+    pc.case_prove(fresh, field, 6, 4, read_big=False)

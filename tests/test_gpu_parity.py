@@ -439,3 +439,13 @@ def test_proof_written_into_pinned_memory_on_gpu(mk, field, log_n):
     from mini_stark_amd.host import build_host_library
     build_host_library()
     thm.check_into_and_slots(mk(field, fresh=True), (1 << log_n) - 1)
+
+
+@pytest.mark.parametrize("field,virtual", [(0, "1"), (1, "1"), (0, "0")])
+def test_virtual_linear_lde_columns(mk, monkeypatch, field, virtual):
+    """r03: the linear LDE columns evaluated row by row inside the leaf-hash kernel (MS_LDE_VIRTUAL; default: AIRs of >= 16 polynomials) instead of being
+    written out by the lincomb kernels - same LDE root, same LDE matrix on ms_lde_read (materialised on demand), same proof, forced on and off."""
+    monkeypatch.setenv("MS_LDE_VIRTUAL", virtual)
+    fresh = lambda f, fresh=False: mk(f, fresh=True)
+    pc.case_prove(fresh, field, 8, 8)
+    pc.case_prove(fresh, field, 6, 4, read_big=False)
