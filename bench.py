@@ -271,7 +271,7 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
 
 def load_sq_profile():
     """VALU wave-instructions per thread per (kernel, grid) from this round's rocprofv3 SQ-counter pass (tools/process_profiles.py)."""
-    for name in ("r02_sq_counters_top_kernels.csv", "r01_sq_counters_top_kernels.csv"):
+    for name in ("r03_sq_counters_top_kernels.csv", "r02_sq_counters_top_kernels.csv", "r01_sq_counters_top_kernels.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             rows = list(csv.DictReader(open(path)))
@@ -413,7 +413,7 @@ def main():
         avg_ms = k["ms"] / max(1, k["launches"])
         achieved = (k["alg_bytes"] / max(1, k["launches"])) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src, pmc_variants = None, None, {}
-        for name in ("r02_pmc_ntt_pass.json", "pmc_ntt_pass.json"):
+        for name in ("r03_pmc_ntt_pass.json", "r02_pmc_ntt_pass.json", "pmc_ntt_pass.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:

@@ -626,7 +626,17 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     T* tile = reinterpret_cast<T*>(lds);
     T* w = tile + (size_t)R * C;                 // [R]: w_r (sub-round twiddles), loaded once per workgroup (MERGE: boundary table tb0, per tile)
     T* twr = w + R;                              // [R]: store twiddle of every tile row (MODE 2: staged coefficients, then tb1 | ts or the row twiddles)
-    const size_t tiles = ((size_t)1 << (p.log_n - K)) >> LC, total = tiles * (size_t)p.nbatch;
+    const size_t tiles = ((size_t)1 << (p.log_n - K)) >> LC;
+    // r03, behind the virtual pass: the per-tile twiddle tables (tb0, tb1 | ts, or the row twiddles) depend on the tile index only, so a workgroup takes ALL batch
+    // entries (columns) of a tile one after the other and builds them once per tile (a slot = a tile; otherwise a slot = one (tile, column) item)
+#ifndef MS_NTT_SHARE
+#define MS_NTT_SHARE 1   // A/B builds: -DMS_NTT_SHARE=0
+#endif
+    // (measured r03, six-column LDE 2^20 -> 2^23: Goldilocks 0.560 -> 0.555 ms; BabyBear 0.333 -> 0.375 ms - its row twiddles are cheap and the hand-over through the
+    //  32-byte tile rows conflicts in LDS - so Goldilocks only)
+    const bool share = MS_NTT_SHARE != 0 && F::ID == 0 && MODE == 2 && p.nbatch > 1 && tiles >= (size_t)nbx && (tiles & 7) == 0 && (nbx & 7) == 0;
+    const size_t total = share ? tiles : tiles * (size_t)p.nbatch;
+    const u32 nin = share ? p.nbatch : 1u;
     const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
     const bool do_scale = p.do_scale != 0;
     // work items of this workgroup: g(i) for i = 0, 1, ..; XCD x = bx & 7 walks the contiguous range [x * total / 8, (x + 1) * total / 8):
@@ -644,7 +654,8 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     static_assert(!(MERGE && SHIFT1) || ((1 << DG::bits(1)) + (1 << BL) * C <= R / 2 && ((C << BL) << DG::bits(1)) <= R / 2), "store table must fit the row-twiddle region");
     if (!MERGE) for (int j = tid; j < R; j += TH) w[j] = p.w_r[j];
     size_t tl, by;
-    locate(base_g + first, tiles, &tl, &by);
+    auto slot_item = [&](size_t slot, u32 bi, size_t* t_, size_t* b_) { if (share) { *t_ = slot; *b_ = bi; } else locate(slot, tiles, t_, b_); };
+    slot_item(base_g + first, 0, &tl, &by);
     constexpr int NS = STAGE ? (R + TH - 1) / TH : 1;
     [[maybe_unused]] T sv[NS];
     auto stage_issue = [&](size_t tile_, size_t by_) {
@@ -658,8 +669,10 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       }
     };
     if constexpr (STAGE) stage_issue(tl, by);
-    for (size_t it = first; it < lim; it += stride) {
-      locate(base_g + it, tiles, &tl, &by);
+    for (size_t it = first; it < lim; it += stride)
+    for (u32 bi = 0; bi < nin; bi++) {
+      slot_item(base_g + it, bi, &tl, &by);
+      [[maybe_unused]] const bool new_tile = bi == 0;      // the tables of this tile are not in LDS yet
       const size_t f0 = tl << LC;
       const bool row_tw = MODE != 0 && !p.last && (f0 >> p.log_Rp) != 0;
       // ---- load: the tile's inputs go to LDS (behind the virtual pass: times w_(r0 r)^(i1 * row)); the row twiddles of this tile
@@ -675,10 +688,12 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       } else {
         // virtual r0-point pass (r0 = C, only the first n/r0 inputs non-zero): A_1[k2*r0 + i1] = w_n^(i1*k) x[k], k = k2 + nprime*row.
         // The k2 part of the twiddle rides on the store twiddle; here x[k] * w_(r0 r)^(i1 * row).  One lane per tile element.
+        // The staged coefficients are handed over through the tile's own column 0 (the expansion leaves that column as it is: i1 = 0 has no twiddle),
+        // so that the table regions keep their content from one batch entry of a tile to the next.
 #pragma unroll
-        for (int j = 0; j < NS; j++) { const int row = tid + j * TH; if (row < R) twr[row] = sv[j]; }
+        for (int j = 0; j < NS; j++) { const int row = tid + j * TH; if (row < R) tile[tix(row, 0)] = sv[j]; }
         msrt::wg_barrier();
-        if constexpr (MERGE) {   // tb0[E0][lo] = w_r^(E0 lo) * w_n^(X E0), X = k_low * Rp (the previous tile's last reader is behind the end-of-tile barrier)
+        if (MERGE && new_tile) {   // tb0[E0][lo] = w_r^(E0 lo) * w_n^(X E0), X = k_low * Rp (the previous tile's last reader is behind the end-of-tile barrier)
           const size_t X = (f0 >> p.log_Rp) << p.log_Rp;
           for (int idx = tid; idx < R; idx += TH) {
             const int e = idx >> DG::slo(0), lo = idx & (Q0 - 1);
@@ -690,14 +705,13 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #pragma unroll VLOAD_UNROLL
         for (int idx = tid; idx < R * C; idx += TH) {
           const int row = idx >> LC, i1 = idx & (C - 1);
-          T v = twr[row];
-          if (i1) v = A::mul_tw(v, p.vtw[(size_t)i1 * row]);
-          tile[tix(row, i1)] = v;
+          if (i1) tile[tix(row, i1)] = A::mul_tw(tile[tix(row, 0)], p.vtw[(size_t)i1 * row]);
         }
       }
       msrt::wg_barrier();
-      if constexpr (MERGE && SHIFT1) {
-        // the staged coefficients have been consumed.  The second boundary is a shift, so the row-twiddle factor of ITS digit E1 moves into the store
+      if (!new_tile) {}   // the tables of this tile are in LDS already (an earlier column of the batch built them)
+      else if constexpr (MERGE && SHIFT1) {
+        // The second boundary is a shift here, so the row-twiddle factor of ITS digit E1 moves into the store
         // table: ts[E1][E2][c] = fa[E1] * fb[E2][c], fa[E1] = w_n^(X E1 2^B0), fb[E2][c] = w_n^(X E2 2^(B0+B1)) * w_n^(k_low c).  fa | fb (2^B1 + 2^BL C
         // entries) are built here, the 2^(B1+BL) C products behind the next barrier (one per thread and tile); ts is read in the store phase.
         const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
@@ -734,10 +748,11 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
           for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);
         }
       }
-      if constexpr (STAGE) {
-        if (it + stride < lim) {   // next tile's coefficients: in flight during the sub-rounds and the store
+      if constexpr (STAGE) {   // the next item's coefficients: in flight during the sub-rounds and the store
+        if (bi + 1 < nin) stage_issue(tl, (size_t)bi + 1);
+        else if (it + stride < lim) {
           size_t ntl, nby;
-          locate(base_g + it + stride, tiles, &ntl, &nby);
+          slot_item(base_g + it + stride, 0, &ntl, &nby);
           stage_issue(ntl, nby);
         }
       }
@@ -745,7 +760,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       msrt::wg_barrier();
       if constexpr (SHIFT1) {
         if constexpr (MERGE) {   // ts[E1][E2][c] = fa[E1] * fb[E2][c] (fa | fb complete behind the barrier above; read in the store phase, behind the next one)
-          if (row_tw) {
+          if (row_tw && new_tile) {
             constexpr int NFA = 1 << DG::bits(1);
             for (int idx = tid; idx < (NFA << BL) * C; idx += TH) {
               const int e1 = idx >> (BL + LC), j = idx & (((1 << BL) * C) - 1);

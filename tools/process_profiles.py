@@ -92,5 +92,48 @@ for extra in ("ntt_lab.log", "latency_probe.txt"):
         shutil.copy(O + "/" + extra, f"profiles/{R}_" + extra)
     except Exception:
         pass
+# ---- BabyBear NTT passes (six-column LDE 2^20 -> 2^23 of tools/ntt_bench.py --field 1): traffic, algorithmic bytes, instructions
+try:
+    Fb = per_dispatch(one(O + "/bb_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
+    Wb = per_dispatch(one(O + "/bb_write/*/*counter_collection.csv"), "WRITE_SIZE")
+    Db = durations(one(O + "/bb_fetch/*/*kernel_trace.csv"))
+    sq = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(one(O + "/bb_sq/*/*counter_collection.csv"))):
+        if "PassKernel" in r["Kernel_Name"] and "false" in r["Kernel_Name"]:
+            sq[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"]); sq[short(r["Kernel_Name"])]["grid"] = float(r["Grid_Size"])
+    bbv, N_, L_ = {}, 1 << 20, 1 << 23
+    alg_launch = 6 * (N_ + L_) * 4 / 2     # (N + L) * s per column with s = 4 bytes, six columns, split over the transform's two passes
+    for k in Fb:
+        if "false" not in k:
+            continue        # the forward (LDE) transforms; the INTT of the three trace columns is not part of the figure
+        f, w, d = Fb[k], Wb.get(k, []), Db.get(k, [])
+        n = min(len(f), len(w), len(d))
+        if not n:
+            continue
+        name = short(k)
+        mode2 = name.rstrip(">").rstrip().endswith(", 2")
+        corr = 2.0 if mode2 or sum(f[:n]) < 0.75 * sum(w[:n]) else 1.0
+        hb = sum(f[i] * 1024 * corr + w[i] * 1024 for i in range(n)) / n; us = sum(d[:n]) / n
+        c = sq.get(name, {})
+        nd = max(1.0, c.get("SQ_WAVE_CYCLES", 0) and n)   # the SQ pass ran the same launches
+        bbv[name] = dict(launches=n, fetch_correction=corr, hbm_bytes_per_launch=hb, avg_us_in_pmc_run=us, TBps_on_traffic=hb / us / 1e6, frac_of_hbm_peak_on_traffic=hb / us / 1e6 / 8.0,
+                         algorithmic_bytes_per_launch=alg_launch, algorithmic_GBps=alg_launch / us / 1e3, frac_of_hbm_peak_algorithmic=alg_launch / us / 1e3 / 8000.0,
+                         traffic_over_algorithmic=hb / alg_launch,
+                         valu_instr_per_element=(c.get("SQ_INSTS_VALU", 0) * 64 / nd) / (6 * L_) if c else None,
+                         salu_instr_per_element=(c.get("SQ_INSTS_SALU", 0) * 64 / nd) / (6 * L_) if c else None,
+                         wave_cycles_waiting_pct=100 * c.get("SQ_WAIT_INST_ANY", 0) / max(1, c.get("SQ_WAVE_CYCLES", 0)) if c else None)
+    rates = [json.loads(l) for l in open(O + "/ntt_bb.log") if l.startswith("{")]
+    json.dump(dict(round=R, what="BabyBear coset LDE 6 x 2^20 -> 2^23 (u32 storage) on msntt::PassKernel2<BB, BB, ., 10, ., ., 3, .> (three sub-rounds; 512 threads x 64 KiB tiles in the "
+                                  "later pass, 256 threads x 32 KiB tiles behind the virtual pass); FETCH_SIZE calibrated as for Goldilocks (tools/process_profiles.py)",
+                   rates_without_profiler=rates, variants=bbv), open(f"profiles/{R}_pmc_ntt_babybear.json", "w"), indent=1)
+    for n_, v in bbv.items():
+        print("  BB", n_, "avg_us %.1f MB/launch %.1f traffic/alg %.2f VALU/elem %s" % (v["avg_us_in_pmc_run"], v["hbm_bytes_per_launch"] / 1e6, v["traffic_over_algorithmic"], v["valu_instr_per_element"]))
+except Exception as e:  # noqa: BLE001
+    print("BabyBear section skipped:", type(e).__name__, e)
+for extra in ("sq_counters_ntt_passes.txt", "single_proof_timeline.txt", "ntt_gl.log", "ntt_bb.log", "sha_lab.log", "stride_probe.log", "io_probe.log"):
+    try:
+        shutil.copy(O + "/" + extra, f"profiles/{R}_" + extra)
+    except Exception:
+        pass
 shutil.copy(O + "/bench_default.json", f"profiles/{R}_bench_default.json")
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step")}), bench["roofline"])

@@ -5,7 +5,7 @@ R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$R
 mkdir -p $O
-python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err   # the driver's command (includes the CPU baselines: ~3.5 minutes)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ntt_lab.hip -o /tmp/ntt_lab 2>/dev/null && /tmp/ntt_lab > $O/ntt_lab.log 2>&1 || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-extras > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --inflight 1 --no-cpu-baseline --no-extras > $O/stats1.log 2>&1
@@ -17,4 +17,13 @@ hipcc --offload-arch=gfx950 -O2 tools/latency_probe.hip -o /tmp/latency_probe 2>
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mini-stark_amd/csrc tools/sha_lab.hip -o /tmp/sha_lab 2>/dev/null && timeout -k 5 100 /tmp/sha_lab > $O/sha_lab.log 2>&1 || true          # SHA-256 on registers only: the hash kernels' ceiling
 hipcc --offload-arch=gfx950 -O3 tools/stride_probe.hip -o /tmp/stride_probe 2>/dev/null && timeout -k 5 120 /tmp/stride_probe > $O/stride_probe.log 2>&1 || true            # access pattern of the NTT later pass, no arithmetic
 timeout -k 10 300 python3 tools/io_probe.py 2>/dev/null | grep '^{' > $O/io_probe.log || true                                                                              # upload / read-back split of the I/O-inclusive rate
+# BabyBear NTT: six-column LDE 2^20 -> 2^23 on the three-sub-round tiles: rates without the profiler, then FETCH / WRITE / SQ passes
+timeout -k 10 200 python3 tools/ntt_bench.py --field 1 --log-rows 20 22 --reps 40 --tag babybear > $O/ntt_bb.log 2>&1 || true
+timeout -k 10 200 python3 tools/ntt_bench.py --field 0 --log-rows 20 24 --reps 40 --tag goldilocks > $O/ntt_gl.log 2>&1 || true
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/bb_fetch -- python3 tools/ntt_bench.py --field 1 --log-rows 20 --reps 3 > $O/bb_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/bb_write -- python3 tools/ntt_bench.py --field 1 --log-rows 20 --reps 3 > $O/bb_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/bb_sq -- python3 tools/ntt_bench.py --field 1 --log-rows 20 --reps 3 > $O/bb_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/gl_sq -- python3 tools/ntt_bench.py --field 0 --log-rows 20 --reps 3 > $O/gl_sq.log 2>&1
+python3 tools/pmc_summary.py $O/gl_sq $O/bb_sq > $O/sq_counters_ntt_passes.txt 2>&1 || true
+rocprofv3 --kernel-trace --output-format csv -d $O/trace1 -- python3 bench.py --inflight 1 --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/trace1.log 2>&1 && python3 tools/trace_gaps.py $O/trace1 > $O/single_proof_timeline.txt 2>&1 || true
 ls $O
