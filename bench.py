@@ -269,6 +269,23 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
     return res, cfg
 
 
+def profile_is_current(round_tag):
+    """True if the committed counter files of `round_tag` were taken from the kernel source this run uses (profiles/<round>_profile_meta.json, written by
+    tools/process_profiles.py); None if there is no record.  A kernel change without re-profiling keeps stale instruction / traffic constants: say so."""
+    import hashlib
+    meta = os.path.join(ROOT, "profiles", round_tag + "_profile_meta.json")
+    if not os.path.exists(meta):
+        return None
+    try:
+        m = json.load(open(meta))
+        h = hashlib.sha256()
+        for fn in m["files"]:
+            h.update(open(os.path.join(ROOT, "mini-stark_amd", "csrc", fn), "rb").read())
+        return h.hexdigest() == m["kernel_source_sha256"]
+    except Exception:
+        return None
+
+
 def load_sq_profile():
     """VALU wave-instructions per thread per (kernel, grid) from this round's rocprofv3 SQ-counter pass (tools/process_profiles.py)."""
     for name in ("r03_sq_counters_top_kernels.csv", "r02_sq_counters_top_kernels.csv", "r01_sq_counters_top_kernels.csv"):
@@ -432,13 +449,16 @@ def main():
                                "traffic_bytes_per_launch": tb, "frac_of_hbm_peak_on_traffic": (tb / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb and a_ms else None}
         allp = prof["ntt_pass"]
         out["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round, gfx950 corrections applied; a constant, not measured in this run)") if traffic_src else None,
+                           "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied; a constant, not measured in this run)") if traffic_src else None,
+                           "traffic_profile_taken_from_this_kernel_source": profile_is_current(traffic_src.split("/")[1][:3]) if traffic_src else None,
                            "frac_on_traffic": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
                            "launches_per_proof": k["launches"], "avg_launch_ms": avg_ms, "alg_bytes_per_launch": k["alg_bytes"] / max(1, k["launches"]),
                            "variants": per_variant,
                            "all_ntt_pass_kernels": {"launches_per_proof": allp["launches"], "ms_per_proof": allp["ms"],
                                                     "alg_GBps": allp["alg_bytes"] / (allp["ms"] * 1e-3) / 1e9 if allp["ms"] else 0.0},
-                           "note": "these passes are bound by the CU's instruction issue, not by HBM: 58-69 % of the VALU issue slots taken (one wave64 instruction per SIMD per 4 clocks), 0.6 scalar instructions per vector one for the exec-masked corrections; a column resident in the Infinity Cache or an LDS-DMA prefetch of the next tile changes nothing (DESIGN.md 6.2, profiles/r02_ntt_tail_dma_ab.log, r02_stride_probe.log)"}
+                           "note": "these passes are not bound by HBM (a column resident in the Infinity Cache or an LDS-DMA prefetch of the next tile changes nothing: profiles/r02_*.log) but by how fast 4 waves per SIMD get "
+                                   "through 64-bit modular arithmetic on 32-bit lanes: r03 SQ counters (profiles/r03_sq_counters_ntt_passes.txt) give 79 / 125 VALU instructions per element (later / first pass; 96 / 139 in r02) "
+                                   "and 0.65 scalar instructions per vector one, issued at one VALU instruction per SIMD per ~9 clocks; DESIGN.md 6.2"}
         tot = sum(v["ms"] for v in prof.values()) or 1.0
         out["kernel_ms_per_proof"] = {n: round(v["ms"], 4) for n, v in prof.items() if v["launches"]}
         out["kernel_ms_total_single_proof"] = tot
@@ -491,6 +511,7 @@ def main():
                                     "peak_measured": peak_meas, "peak_measured_basis": "3.4 cycles per VALU instruction: what register-resident integer butterfly code sustains at >= 4 waves/SIMD whatever the opcode mix "
                                     "(tools/ntt_lab.hip, profiles/r02_ntt_lab.log); the per-opcode costs of tools/valu_rate.hip did not carry over to mixed code",
                                     "instr_source": "profiles/" + sq_name + " (rocprofv3 --pmc SQ_INSTS_VALU per dispatch; constants, not measured in this run)",
+                                    "instr_profile_taken_from_this_kernel_source": profile_is_current(sq_name[:3]),
                                     "times": "live: HIP events of this run, one proof alone (small tree levels are latency-bound, which lowers the class average)", "kernels": rv}
 
         if world == 1 and not args.no_extras and args.log_rows == 20 and args.field == 0:

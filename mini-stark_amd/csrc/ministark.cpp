@@ -489,11 +489,18 @@ template <class F> struct Ctx : CtxBase {
     return launch_v2i<msntt::PassKernel2<F, typename msntt::NttArith<F>::type, INV, K, LC, 256, 2, MODE>>(pp, coop_grid(tiles * batch), 2, MODE, K, LC);
   }
   // persistent grid of the cooperative pass kernels: two workgroups per CU (their 72-80 KiB of LDS), a multiple of 8 (XCD-aware tile walk)
-  int ntt_coop_wgs = 512;
+  int ntt_coop_wgs = 512, ntt_share = 1;   // MS_NTT_SHARE=0: never the shared-table instance (A/B)
   unsigned coop_grid(size_t work_items, int per_cu = 2) const { const size_t g = (size_t)ntt_coop_wgs * per_cu / 2; return (unsigned)(work_items < g ? work_items : g); }
   template <bool INV, int K, int LC>
   int launch_v2(const msntt::PassParams<F>& pp, size_t tiles, size_t batch) {
-    if (pp.log_r0) { if constexpr (LC == 3) return launch_v2m<INV, K, LC, 2>(pp, tiles, batch); else return 996; }
+    if (pp.log_r0) {
+      if constexpr (LC == 3) {
+        // Goldilocks, several columns, enough tiles to feed the persistent grid one tile at a time: the instance that builds the per-tile twiddle tables once
+        // per tile for all columns (MODE 3; measured r03: six-column LDE 0.560 -> 0.555 ms; BabyBear 0.333 -> 0.375 ms, so not for it)
+        if constexpr (F::ID == 0 && K == 10) { if (ntt_v2_sub3 && ntt_share && batch > 1 && tiles >= (size_t)coop_grid(tiles * batch) && (tiles & 7) == 0) return launch_v2m<INV, K, LC, 3>(pp, tiles, batch); }
+        return launch_v2m<INV, K, LC, 2>(pp, tiles, batch);
+      } else return 996;
+    }
     if (pp.log_Rp == 0) return launch_v2m<INV, K, LC, 0>(pp, tiles, batch);
     return launch_v2m<INV, K, LC, 1>(pp, tiles, batch);
   }
@@ -806,6 +813,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_V2")) ntt_v2 = atoi(e);
     if (const char* e = getenv("MS_NTT_V2_SUB3")) ntt_v2_sub3 = atoi(e);
     if (const char* e = getenv("MS_NTT_V2_REGPASS")) ntt_v2_regpass = atoi(e);
+    if (const char* e = getenv("MS_NTT_SHARE")) ntt_share = atoi(e);
     if (const char* e = getenv("MS_NTT_COOP_WGS")) { int v = atoi(e); if (v >= 8 && v <= 65536) ntt_coop_wgs = v & ~7; }
     if (const char* e = getenv("MS_NTT_V2_MAXPASS")) { int v = atoi(e); if (v >= 1 && v <= 4) ntt_v2_maxpass = v; }
     if (const char* e = getenv("MS_NTT_COLBATCH")) ntt_colbatch = atoi(e);

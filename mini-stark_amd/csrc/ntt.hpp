@@ -470,6 +470,10 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
   typedef PassParams<F> Params;
   typedef Digits2<K, NSUB> DG;
   typedef A Arith;
+  // MODE 3 = MODE 2 (first pass behind the virtual pass) with the per-tile twiddle tables SHARED by the batch entries of a tile: a separate instance, because
+  // the extra loop level costs the plain one registers (r03: 120 VGPRs without, 128 + 22 spilled dwords with the choice made at run time)
+  static constexpr int PM = (MODE == 3) ? 2 : MODE;
+  static constexpr bool SHARE = MODE == 3;
   static constexpr bool INVERSE = INV;
   static constexpr int THREADS = TH;
   static constexpr int R = 1 << K, C = 1 << LC;
@@ -479,7 +483,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
   static constexpr int MIN_WAVES = (TH >= 512 || (sizeof(T) == 4 && K == 10 && LC == 3 && NSUB == 3)) ? 4 : 2;
   static_assert(K >= 7 && K <= 10 && DG::bits(0) <= 5 && BL >= 2 && C % VEC == 0 && TH % LPR == 0 && R % RPS == 0 && (NSUB == 2 || NSUB == 3), "unsupported tile");
   static_assert(NSUB == 2 || DG::bits(1) >= 2, "middle digit");
-  static_assert(MODE >= 0 && MODE <= 2, "MODE");
+  static_assert(PM >= 0 && PM <= 2, "PM");
   typedef T V16 __attribute__((vector_size(16)));   // one 16-byte global / LDS access
 
   // tile | w_r [R] | store twiddle of every tile row [R] (filled in the load phase, while the tile's global loads are in flight)
@@ -493,14 +497,14 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #define MS_NTT_SHIFT1 1   // 1: plain first pass and later passes (measured r03: later pass 83 -> 79 VALU instructions per element, 239 -> 234 us per six-column launch);
                           // 2: also behind the virtual pass (126.7 -> 124.9 instructions, but 296 -> 303 us: bank conflicts of the bigger store table + scalar work); 0: off
 #endif
-  static constexpr bool SHIFT1 = MS_NTT_SHIFT1 != 0 && (MODE != 2 || MS_NTT_SHIFT1 == 2) && F::ID == 0 && NSUB == 3 && (TH / 64) == (1 << DG::slo(1)) && ((C << DG::bits(0)) % 64) == 0 && (64 % C) == 0 &&
+  static constexpr bool SHIFT1 = MS_NTT_SHIFT1 != 0 && (PM != 2 || MS_NTT_SHIFT1 == 2) && F::ID == 0 && NSUB == 3 && (TH / 64) == (1 << DG::slo(1)) && ((C << DG::bits(0)) % 64) == 0 && (64 % C) == 0 &&
                                  DG::bits(0) >= 2 && DG::bits(1) >= 2 && DG::bits(1) + BL <= 6 &&
-                                 (MODE != 2 || ((C << BL) << DG::bits(1)) <= R / 2);   // behind the virtual pass the store table [E1][E2][c] must fit half the row-twiddle region
+                                 (PM != 2 || ((C << BL) << DG::bits(1)) <= R / 2);   // behind the virtual pass the store table [E1][E2][c] must fit half the row-twiddle region
   static MS_HD int prow(int row) { return row ^ ((row >> BL) & 3) ^ (SHIFT1 ? ((row >> DG::slo(0)) & 3) : 0); }
   static MS_HD int tix(int row, int c) { return prow(row) * C + c; }
   static MS_HD int mode_of(const Params& p) { return p.log_r0 ? 2 : (p.log_Rp == 0 ? 0 : 1); }
   static MS_HD bool applicable(const Params& p) {
-    return p.log_r == K && p.log_C == LC && p.log_rho == 0 && mode_of(p) == MODE &&
+    return p.log_r == K && p.log_C == LC && p.log_rho == 0 && mode_of(p) == PM && (!SHARE || p.nbatch > 1) &&
            ((p.log_r0 == 0 && (p.log_Rp == 0 || p.log_Rp >= LC)) || (p.log_r0 == LC && p.log_Rp == LC));
   }
   static MS_DEV T tw_global(const Params& p, size_t e) {
@@ -592,25 +596,25 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
   // butterflies is exactly the 16-byte pieces of the store - no write-back of the last sub-round, no read-back for the store, one
   // barrier less per tile.
   static constexpr int TAIL_ITEMS = (R >> BL) * LPR, NJT = (TAIL_ITEMS + TH - 1) / TH;
-  static constexpr bool FUSE_TAIL = MODE != 0 && NSUB == 3 && TAIL_ITEMS % TH == 0;
+  static constexpr bool FUSE_TAIL = PM != 0 && NSUB == 3 && TAIL_ITEMS % TH == 0;
   // Behind the virtual pass: the tile's R coefficients (one gather each) are fetched ONE TILE AHEAD into NS registers per thread and handed to
   // the expanding lanes through LDS (the row-twiddle region, free at that point): R gathers per tile instead of R * C broadcast loads.
-  static constexpr bool STAGE = MODE == 2;
+  static constexpr bool STAGE = PM == 2;
   // ... and an element meets five twiddles there: the virtual pass's at the load, two sub-round boundaries, and at the store w_n^(8 k2 i_new)
   // (row) and w_n^(k2 i1) (column).  i_new = E0 + 2^B0 E1 + 2^(B0+B1) E2 (one output digit per sub-round), so the row twiddle is a product of
   // one factor per digit: the factors of E0 and E1 ride on the boundary tables (per tile: tb0[E0][lo] in the w region, tb1[E1][lo] in the
   // row-twiddle region) and the factor of the last digit is merged with the column twiddle into ts[E_last][i1] - FOUR multiplications per
   // element instead of five.  All factors are exact field elements, so the regrouping does not change a bit of the result.
   // Goldilocks only: BabyBear's butterflies read w_r inside the sub-rounds, so its w region cannot be given away.
-  static constexpr bool MERGE = MODE == 2 && F::ID == 0;
+  static constexpr bool MERGE = PM == 2 && F::ID == 0;
   static constexpr int VLOAD_UNROLL = 4;   // twiddle gathers in flight per thread in the expansion behind the virtual pass
   static MS_DEV void locate(size_t g, size_t tiles, size_t* tile, size_t* by) { *by = g / tiles; *tile = g - *by * tiles; }
-  // MODE 0 / 1: the tile's rows, SWEEPS 16-byte pieces per lane (fully unrolled: `rows` never leaves the register file)
+  // PM 0 / 1: the tile's rows, SWEEPS 16-byte pieces per lane (fully unrolled: `rows` never leaves the register file)
   static MS_DEV void load_rows(const Params& p, size_t tile, size_t by, int tid, V16 (&rows)[SWEEPS]) {
     const size_t n = (size_t)1 << p.log_n, cs = n >> K, f0 = tile << LC;
     const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
     const T* s0 = p.src + by * p.src_bstride + f0 + c0 + (size_t)rb * cs;
-    if (MODE == 1 || p.n_in >= n) {
+    if (PM == 1 || p.n_in >= n) {
 #pragma unroll
       for (int i = 0; i < SWEEPS; i++) rows[i] = *reinterpret_cast<const V16*>(s0 + (size_t)(i * RPS) * cs);
     } else {
@@ -625,16 +629,13 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
   static MS_DEV void run(const Params& p, int bx, int, int nbx, int tid, unsigned char* lds) {
     T* tile = reinterpret_cast<T*>(lds);
     T* w = tile + (size_t)R * C;                 // [R]: w_r (sub-round twiddles), loaded once per workgroup (MERGE: boundary table tb0, per tile)
-    T* twr = w + R;                              // [R]: store twiddle of every tile row (MODE 2: staged coefficients, then tb1 | ts or the row twiddles)
+    T* twr = w + R;                              // [R]: store twiddle of every tile row (PM 2: staged coefficients, then tb1 | ts or the row twiddles)
     const size_t tiles = ((size_t)1 << (p.log_n - K)) >> LC;
     // r03, behind the virtual pass: the per-tile twiddle tables (tb0, tb1 | ts, or the row twiddles) depend on the tile index only, so a workgroup takes ALL batch
     // entries (columns) of a tile one after the other and builds them once per tile (a slot = a tile; otherwise a slot = one (tile, column) item)
-#ifndef MS_NTT_SHARE
-#define MS_NTT_SHARE 1   // A/B builds: -DMS_NTT_SHARE=0
-#endif
     // (measured r03, six-column LDE 2^20 -> 2^23: Goldilocks 0.560 -> 0.555 ms; BabyBear 0.333 -> 0.375 ms - its row twiddles are cheap and the hand-over through the
     //  32-byte tile rows conflicts in LDS - so Goldilocks only)
-    const bool share = MS_NTT_SHARE != 0 && F::ID == 0 && MODE == 2 && p.nbatch > 1 && tiles >= (size_t)nbx && (tiles & 7) == 0 && (nbx & 7) == 0;
+    constexpr bool share = SHARE;   // the launcher picks this instance when tiles >= grid, tiles % 8 == 0 and the launch has more than one column
     const size_t total = share ? tiles : tiles * (size_t)p.nbatch;
     const u32 nin = share ? p.nbatch : 1u;
     const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
@@ -642,7 +643,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     // work items of this workgroup: g(i) for i = 0, 1, ..; XCD x = bx & 7 walks the contiguous range [x * total / 8, (x + 1) * total / 8):
     // behind the virtual pass its workgroups share 64-byte source lines through that XCD's L2; in a later pass the 64 tiles an XCD works on
     // at a time are 4 KiB runs of every row
-    const bool xcd_map = MODE != 0 && (nbx & 7) == 0 && (total & 7) == 0 && total >= 64;
+    const bool xcd_map = PM != 0 && (nbx & 7) == 0 && (total & 7) == 0 && total >= 64;
     const size_t stride = xcd_map ? (size_t)(nbx >> 3) : (size_t)nbx, first = xcd_map ? (size_t)(bx >> 3) : (size_t)bx;
     const size_t lim = xcd_map ? (total >> 3) : total, base_g = xcd_map ? (size_t)(bx & 7) * (total >> 3) : 0;
     if (first >= lim) return;
@@ -669,14 +670,70 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       }
     };
     if constexpr (STAGE) stage_issue(tl, by);
-    for (size_t it = first; it < lim; it += stride)
+    // per-tile twiddle tables behind the virtual pass
+    [[maybe_unused]] auto build_tb0 = [&](size_t f0) {   // tb0[E0][lo] = w_r^(E0 lo) * w_n^(X E0), X = k_low * Rp (the previous tile's last reader is behind the end-of-tile barrier)
+      const size_t X = (f0 >> p.log_Rp) << p.log_Rp;
+      for (int idx = tid; idx < R; idx += TH) {
+        const int e = idx >> DG::slo(0), lo = idx & (Q0 - 1);
+        T v = p.w_r[e * lo];
+        if (X && e) v = A::mul_tw(v, tw_global(p, X * (size_t)e));
+        w[idx] = v;
+      }
+    };
+    [[maybe_unused]] auto build_tables = [&](size_t f0, bool row_tw) {
+      if constexpr (MERGE && SHIFT1) {
+        // The second boundary is a shift here, so the row-twiddle factor of ITS digit E1 moves into the store
+        // table: ts[E1][E2][c] = fa[E1] * fb[E2][c], fa[E1] = w_n^(X E1 2^B0), fb[E2][c] = w_n^(X E2 2^(B0+B1)) * w_n^(k_low c).  fa | fb (2^B1 + 2^BL C
+        // entries) are built here, the 2^(B1+BL) C products behind the next barrier (one per thread and tile); ts is read in the store phase.
+        const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
+        constexpr int NFA = 1 << DG::bits(1);
+        for (int idx = tid; idx < NFA + (1 << BL) * C; idx += TH) {
+          T v;
+          if (idx < NFA) v = tw_global(p, (X * (size_t)idx) << B0);
+          else {
+            const int j = idx - NFA, e = j >> LC, c = j & (C - 1);           // last digit x column
+            v = tw_global(p, (X * (size_t)e) << (K - BL));
+            if (k_low && c) v = A::mul_tw(v, tw_global(p, k_low * (size_t)c));
+          }
+          twr[idx] = v;
+        }
+      } else if constexpr (MERGE) {   // tb1 (read in the second sub-round) and ts (read in the store phase)
+        const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
+        for (int idx = tid; idx < NTB1 + (1 << BL) * C; idx += TH) {
+          T v;
+          if (idx < NTB1) {
+            const int e = idx >> DG::slo(1), lo = idx & (Q1 - 1);
+            v = p.w_r[(e * lo) << B0];                                        // w_(Q1 2^B1)^(e lo)
+            if (X && e) v = A::mul_tw(v, tw_global(p, (X * (size_t)e) << B0));
+            tb1[idx] = v;
+          } else {
+            const int j = idx - NTB1, e = j >> LC, c = j & (C - 1);           // last digit x column
+            v = tw_global(p, (X * (size_t)e) << (K - BL));
+            if (k_low && c) v = A::mul_tw(v, tw_global(p, k_low * (size_t)c));
+            ts[j] = v;
+          }
+        }
+      } else if constexpr (STAGE) {   // no merged tables (BabyBear): the row twiddles (read in the store phase)
+        if (row_tw) {
+          const size_t k_low = f0 >> p.log_Rp;
+          for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);
+        }
+      }
+    };
+    for (size_t it = first; it < lim; it += stride) {
+    if constexpr (SHARE) {   // the tile's tables, once for all its batch entries (the previous tile's last readers are behind its end-of-tile barrier)
+      const size_t f0t = (base_g + it) << LC;
+      if constexpr (MERGE) build_tb0(f0t);
+      build_tables(f0t, !p.last && (f0t >> p.log_Rp) != 0);
+      msrt::wg_barrier();
+    }
     for (u32 bi = 0; bi < nin; bi++) {
       slot_item(base_g + it, bi, &tl, &by);
-      [[maybe_unused]] const bool new_tile = bi == 0;      // the tables of this tile are not in LDS yet
+      [[maybe_unused]] const bool new_tile = bi == 0;
       const size_t f0 = tl << LC;
-      const bool row_tw = MODE != 0 && !p.last && (f0 >> p.log_Rp) != 0;
+      const bool row_tw = PM != 0 && !p.last && (f0 >> p.log_Rp) != 0;
       // ---- load: the tile's inputs go to LDS (behind the virtual pass: times w_(r0 r)^(i1 * row)); the row twiddles of this tile
-      if constexpr (MODE != 2) {
+      if constexpr (PM != 2) {
         V16 rows[SWEEPS];
         load_rows(p, tl, by, tid, rows);
         if (row_tw) {
@@ -693,61 +750,27 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #pragma unroll
         for (int j = 0; j < NS; j++) { const int row = tid + j * TH; if (row < R) tile[tix(row, 0)] = sv[j]; }
         msrt::wg_barrier();
-        if (MERGE && new_tile) {   // tb0[E0][lo] = w_r^(E0 lo) * w_n^(X E0), X = k_low * Rp (the previous tile's last reader is behind the end-of-tile barrier)
-          const size_t X = (f0 >> p.log_Rp) << p.log_Rp;
-          for (int idx = tid; idx < R; idx += TH) {
-            const int e = idx >> DG::slo(0), lo = idx & (Q0 - 1);
-            T v = p.w_r[e * lo];
-            if (X && e) v = A::mul_tw(v, tw_global(p, X * (size_t)e));
-            w[idx] = v;
-          }
-        }
+        if constexpr (MERGE && !SHARE) build_tb0(f0);
+        if constexpr (!SHIFT1 && TH % C == 0 && (((TH >> LC) >> BL) & 3) == 0) {
+          // a thread's elements are (row r0 + k * TH/C, column i1): the rows' swizzle term is the same for all k, so every address is base + k * constant
+          constexpr int RSTEP = TH >> LC;
+          const int i1 = tid & (C - 1), r0 = tid >> LC;
+          T* tp = tile + (((r0 ^ ((r0 >> BL) & 3)) << LC));
+          if (i1) {
+            const T* vt = p.vtw + (size_t)i1 * r0;
 #pragma unroll VLOAD_UNROLL
-        for (int idx = tid; idx < R * C; idx += TH) {
-          const int row = idx >> LC, i1 = idx & (C - 1);
-          if (i1) tile[tix(row, i1)] = A::mul_tw(tile[tix(row, 0)], p.vtw[(size_t)i1 * row]);
+            for (int k = 0; k < R / RSTEP; k++) tp[i1 + k * RSTEP * C] = A::mul_tw(tp[k * RSTEP * C], vt[(size_t)i1 * (RSTEP * k)]);
+          }
+        } else {
+#pragma unroll VLOAD_UNROLL
+          for (int idx = tid; idx < R * C; idx += TH) {
+            const int row = idx >> LC, i1 = idx & (C - 1);
+            if (i1) tile[tix(row, i1)] = A::mul_tw(tile[tix(row, 0)], p.vtw[(size_t)i1 * row]);
+          }
         }
       }
       msrt::wg_barrier();
-      if (!new_tile) {}   // the tables of this tile are in LDS already (an earlier column of the batch built them)
-      else if constexpr (MERGE && SHIFT1) {
-        // The second boundary is a shift here, so the row-twiddle factor of ITS digit E1 moves into the store
-        // table: ts[E1][E2][c] = fa[E1] * fb[E2][c], fa[E1] = w_n^(X E1 2^B0), fb[E2][c] = w_n^(X E2 2^(B0+B1)) * w_n^(k_low c).  fa | fb (2^B1 + 2^BL C
-        // entries) are built here, the 2^(B1+BL) C products behind the next barrier (one per thread and tile); ts is read in the store phase.
-        const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
-        constexpr int NFA = 1 << DG::bits(1);
-        for (int idx = tid; idx < NFA + (1 << BL) * C; idx += TH) {
-          T v;
-          if (idx < NFA) v = tw_global(p, (X * (size_t)idx) << B0);
-          else {
-            const int j = idx - NFA, e = j >> LC, c = j & (C - 1);           // last digit x column
-            v = tw_global(p, (X * (size_t)e) << (K - BL));
-            if (k_low && c) v = A::mul_tw(v, tw_global(p, k_low * (size_t)c));
-          }
-          twr[idx] = v;
-        }
-      } else if constexpr (MERGE) {   // the staged coefficients have been consumed: the region takes tb1 (read after the next barrier) and ts (read in the store phase)
-        const size_t k_low = f0 >> p.log_Rp, X = k_low << p.log_Rp;
-        for (int idx = tid; idx < NTB1 + (1 << BL) * C; idx += TH) {
-          T v;
-          if (idx < NTB1) {
-            const int e = idx >> DG::slo(1), lo = idx & (Q1 - 1);
-            v = p.w_r[(e * lo) << B0];                                        // w_(Q1 2^B1)^(e lo)
-            if (X && e) v = A::mul_tw(v, tw_global(p, (X * (size_t)e) << B0));
-            tb1[idx] = v;
-          } else {
-            const int j = idx - NTB1, e = j >> LC, c = j & (C - 1);           // last digit x column
-            v = tw_global(p, (X * (size_t)e) << (K - BL));
-            if (k_low && c) v = A::mul_tw(v, tw_global(p, k_low * (size_t)c));
-            ts[j] = v;
-          }
-        }
-      } else if constexpr (STAGE) {   // the staged coefficients have been consumed: the region takes the row twiddles (read in the store phase)
-        if (row_tw) {
-          const size_t k_low = f0 >> p.log_Rp;
-          for (int row = tid; row < R; row += TH) twr[row] = tw_global(p, ((size_t)row_to_inew(row) * k_low) << p.log_Rp);
-        }
-      }
+      if constexpr (!SHARE) build_tables(f0, row_tw);   // (SHARE: built once per tile, ahead of its batch entries)
       if constexpr (STAGE) {   // the next item's coefficients: in flight during the sub-rounds and the store
         if (bi + 1 < nin) stage_issue(tl, (size_t)bi + 1);
         else if (it + stride < lim) {
@@ -780,7 +803,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         constexpr int NE = 1 << BL, B0_ = DG::bits(0), B1_ = DG::bits(1);
         const size_t k_low = f0 >> p.log_Rp;
         T* outb = dst + ((k_low << p.log_Rp) << K) + (f0 & (((size_t)1 << p.log_Rp) - 1));
-        const bool col_tw = row_tw && MODE == 2 && !MERGE;
+        const bool col_tw = row_tw && PM == 2 && !MERGE;
         V16 o[NJT][NE];
 #pragma unroll
         for (int J = 0; J < NJT; J++) {
@@ -820,12 +843,12 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
       }
       if constexpr (NSUB >= 3) { sub_items<2, 0>(tid, tile, w); msrt::wg_barrier(); }
       // ---- store
-      if constexpr (MODE != 0) {
+      if constexpr (PM != 0) {
         // out = k_low*Rp*r + i_done + Rp*i_new: a tile row is one 16*LPR-byte run
         const size_t k_low = f0 >> p.log_Rp, i_done0 = (f0 & (((size_t)1 << p.log_Rp) - 1)) + c0;
         T* out = dst + ((k_low << p.log_Rp) << K) + i_done0;
         T gc[VEC];                                     // behind the virtual pass: w_n^(k_low * i_done), i_done = the column
-        const bool col_tw = row_tw && MODE == 2 && !MERGE;
+        const bool col_tw = row_tw && PM == 2 && !MERGE;
 #pragma unroll
         for (int v = 0; v < VEC; v++) gc[v] = col_tw ? tw_global(p, k_low * (size_t)(c0 + v)) : F::to_tw(F::from_u64(1));
 #pragma unroll 2
@@ -863,6 +886,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         }
       }
       msrt::wg_barrier();   // the tile and its row twiddles are free for the next work item
+    }
     }
   }
 };

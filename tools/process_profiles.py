@@ -43,7 +43,7 @@ for k in F:
     # pass (modes 0, 1) reads exactly as many bytes as it writes, and WRITE_SIZE is exact: the factor is 2 when the raw count is half of that (both halves of
     # a line asked for by the same XCD's L2: the XCD-contiguous tile walk), 1 when it equals it (r02's first walk: neighbouring 64-byte pieces went to
     # different XCDs).  Mode 2 (8-byte gathers + L2-resident tables): the guide's x2 kept as an upper bound.
-    mode2 = name.rstrip(">").rstrip().endswith(", 2")
+    mode2 = name.rstrip(">").rstrip().endswith((", 2", ", 3"))
     corr = 2.0 if mode2 or sum(f[:n]) < 0.75 * sum(w[:n]) else 1.0
     per = [dict(fetch_raw_bytes=f[i] * 1024, fetch_bytes=f[i] * 1024 * corr, write_bytes=w[i] * 1024, hbm_bytes=f[i] * 1024 * corr + w[i] * 1024, us_in_pmc_run=d[i],
                 TBps_on_traffic=(f[i] * 1024 * corr + w[i] * 1024) / d[i] / 1e6) for i in range(n)]
@@ -54,7 +54,7 @@ rv = variants.get(roof) or next(iter(variants.values()))
 s8 = 8
 alg = dict(lde_3_columns=3 * ((1 << 20) + (1 << 23)) * s8, fri_round0_1_column=((1 << 20) + (1 << 23)) * s8)
 big = lambda name: max(x["hbm_bytes"] for x in variants[name]["per_launch"]) if name in variants else 0.0   # the 3-column launch of that kernel
-lde_traffic = sum(big(n) for n in variants if ", false," in n and (n.rstrip(">").rstrip().endswith(", 2") or n.rstrip(">").rstrip().endswith(", 1")))
+lde_traffic = sum(big(n) for n in variants if ", false," in n and n.rstrip(">").rstrip().endswith((", 1", ", 2", ", 3")))
 json.dump(dict(kernel=roof, round=R, launches=rv["launches"], hbm_bytes_per_launch=rv["hbm_bytes_per_launch"],
                method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-extras` "
                       "(2 proofs: per proof one 3-column LDE and one 1-column FRI round-0 transform, each two launches; plus the 3-column INTT). Counter unit KB (x1024). "
@@ -111,7 +111,7 @@ try:
         if not n:
             continue
         name = short(k)
-        mode2 = name.rstrip(">").rstrip().endswith(", 2")
+        mode2 = name.rstrip(">").rstrip().endswith((", 2", ", 3"))
         corr = 2.0 if mode2 or sum(f[:n]) < 0.75 * sum(w[:n]) else 1.0
         hb = sum(f[i] * 1024 * corr + w[i] * 1024 for i in range(n)) / n; us = sum(d[:n]) / n
         c = sq.get(name, {})
@@ -136,4 +136,10 @@ for extra in ("sq_counters_ntt_passes.txt", "single_proof_timeline.txt", "ntt_gl
     except Exception:
         pass
 shutil.copy(O + "/bench_default.json", f"profiles/{R}_bench_default.json")
+# which kernel source these counters belong to: bench.py compares it with the source it runs (a kernel change without re-profiling shows as stale)
+import hashlib
+hsh = hashlib.sha256()
+for fn in ("ntt.hpp", "field.hpp", "merkle.hpp", "poly.hpp"):
+    hsh.update(open(os.path.join("mini-stark_amd", "csrc", fn), "rb").read())
+json.dump({"round": R, "kernel_source_sha256": hsh.hexdigest(), "files": ["ntt.hpp", "field.hpp", "merkle.hpp", "poly.hpp"]}, open(f"profiles/{R}_profile_meta.json", "w"))
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step")}), bench["roofline"])
