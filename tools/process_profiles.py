@@ -54,7 +54,9 @@ rv = variants.get(roof) or next(iter(variants.values()))
 s8 = 8
 alg = dict(lde_3_columns=3 * ((1 << 20) + (1 << 23)) * s8, fri_round0_1_column=((1 << 20) + (1 << 23)) * s8)
 big = lambda name: max(x["hbm_bytes"] for x in variants[name]["per_launch"]) if name in variants else 0.0   # the 3-column launch of that kernel
-lde_traffic = sum(big(n) for n in variants if ", false," in n and n.rstrip(">").rstrip().endswith((", 1", ", 2", ", 3")))
+fwd = [n for n in variants if ", false," in n]
+first = [n for n in fwd if n.rstrip(">").rstrip().endswith(", 3")] or [n for n in fwd if n.rstrip(">").rstrip().endswith(", 2")]   # the 3-column LDE's first pass: the shared-table instance since r03
+lde_traffic = sum(big(n) for n in first[:1] + [n for n in fwd if n.rstrip(">").rstrip().endswith(", 1")][:1])
 json.dump(dict(kernel=roof, round=R, launches=rv["launches"], hbm_bytes_per_launch=rv["hbm_bytes_per_launch"],
                method="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-extras` "
                       "(2 proofs: per proof one 3-column LDE and one 1-column FRI round-0 transform, each two launches; plus the 3-column INTT). Counter unit KB (x1024). "
