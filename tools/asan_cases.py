@@ -34,4 +34,23 @@ del os.environ["MS_NTT_V2_REGPASS"]
 # fused last sub-round + store: 2^8-row tiles in both modes (2^16 coefficients behind the virtual pass) and the 2^10-row tiles of a plain 2^20-point transform
 pc.case_coset_lde(lambda f, fresh=False: mk(f, fresh=True), 0, 16, 8)
 pc.case_ntt(lambda f, fresh=False: mk(f, fresh=True), 0, 20, batch=1)
+# r03: BabyBear on the three-sub-round tiles (2^19 points: 2^10 x 2^9 plain; 2^17 coefficients behind the virtual pass), the shared-table first pass
+# (needs tiles >= workgroups: MS_NTT_COOP_WGS=8), the virtual linear LDE columns, the arithmetic self test, the proof written into a caller buffer
+pc.case_ntt(lambda f, fresh=False: mk(f, fresh=True), 1, 19, batch=1)
+pc.case_coset_lde(lambda f, fresh=False: mk(f, fresh=True), 1, 17, 8)
+os.environ["MS_NTT_COOP_WGS"] = "8"
+pc.case_coset_lde(lambda f, fresh=False: mk(f, fresh=True), 0, 17, 8)
+del os.environ["MS_NTT_COOP_WGS"]
+os.environ["MS_LDE_VIRTUAL"] = "1"
+for field in (0, 1):
+    pc.case_prove(lambda f, fresh=False: mk(f, fresh=True), field, 6, 8)
+del os.environ["MS_LDE_VIRTUAL"]
+for field in (0, 1):
+    pc.case_arith_selftest(mk, field, nrand=256)
+from mini_stark_amd.host import build_host_library
+build_host_library()
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import test_host_mirror as thm
+for field in (0, 1):
+    thm.check_into_and_slots(ms.Context(field, lib_path=EMU), 31)
 print("asan run complete")

@@ -11,4 +11,5 @@ export MS_EMU_LIB="$OUT" ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-fi
 python tools/asan_cases.py
 ( cd tests && python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29931 shard_worker.py 0 8 8 16 2>&1 | grep -E '^\{|ERROR|runtime error' )
 ( cd tests && python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29932 shard_worker.py 1 8 4 16 2>&1 | grep -E '^\{|ERROR|runtime error' )
+( cd tests && MS_SHARD_SLICES=4 MS_SHARD_SLICE_MIN=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29933 shard_worker.py 0 9 8 16 2>&1 | grep -E '^\{|ERROR|runtime error' )   # sliced digest exchange
 echo "sanitizer run clean"
