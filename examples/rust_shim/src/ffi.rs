@@ -52,6 +52,8 @@ extern "C" {
     pub fn ms_lde_read(ctx: *mut ms_ctx, out_rowmajor: *mut u64) -> c_int;
     pub fn ms_mix(ctx: *mut ms_ctx, r: u64) -> c_int;
     pub fn ms_validity_read(ctx: *mut ms_ctx, out: *mut u64) -> c_int;
+    pub fn ms_mix_cubic(ctx: *mut ms_ctx, r: u64, spec: *const c_int, s: *const u64, ncons: c_int) -> c_int;
+    pub fn ms_validity_len(ctx: *const ms_ctx) -> usize;
     pub fn ms_eval_ext(ctx: *mut ms_ctx, z: *const u64, q: c_int, out: *mut u64) -> c_int;
     // ---- Fri::prove stages (src/fri.rs:53-189)
     pub fn ms_fri_begin(ctx: *mut ms_ctx, blowup: usize, rounds: usize, root0: *mut u8) -> c_int;

@@ -136,7 +136,15 @@ int ms_lde_commit(ms_ctx* ctx, size_t blowup, uint64_t shift, size_t lpn, uint8_
 int ms_lde_read(ms_ctx* ctx, uint64_t* out_rowmajor /* L*c */);
 /* 1.3  validity = sum_i r^i f_i (remainder of divide_by_vanishing_poly; quirk Q1).  starks.rs:108-119. */
 int ms_mix(ms_ctx* ctx, uint64_t r);
-int ms_validity_read(ms_ctx* ctx, uint64_t* out /* N */);
+int ms_validity_read(ms_ctx* ctx, uint64_t* out /* ms_validity_len(ctx): N, or 2N after ms_mix_cubic */);
+/* BUILD-DEFINED, no reference counterpart (BASELINE configs[4] "degree-3 constraints"; the reference cannot express them: its validity polynomial is the
+ * remainder of divide_by_vanishing_poly, starks.rs:118-119, quirk Q1).  In place of ms_mix, with the TRUE quotient:
+ *   C_t(x) = P_j(w x) - P_a(x) P_b(x) P_c(x) - s_t P_d(x)         spec[t] = {j, a, b, c, d} (polynomial indices), w = the trace domain's generator
+ *   validity(x) = (sum_t r^t C_t(x)) (x - w^(N-1)) / (x^N - 1)     2N coefficients; MS_ERR_SHAPE if the division is not exact (a row 0..N-2 violates a constraint)
+ * Evaluated on the LDE domain of the preceding ms_lde_commit (blowup >= 4), interpolated back.  ms_eval_ext / ms_validity_read / ms_fri_begin then work on the
+ * 2N-coefficient validity polynomial.  Checked against a big-integer restatement in the tests; self-verified at full size. */
+int ms_mix_cubic(ms_ctx* ctx, uint64_t r, const int* spec /* [ncons][5] */, const uint64_t* s /* [ncons] */, int ncons);
+size_t ms_validity_len(const ms_ctx* ctx);
 /* 2.   DEEP-ALI: out[t][i] = f_i(z_t) for the c constraint polys, out[t][c] = validity(z_t);
  *      z: q*E limbs, out: q*(c+1)*E limbs.  starks.rs:124-151, field.rs:23-32. */
 int ms_eval_ext(ms_ctx* ctx, const uint64_t* z, int q, uint64_t* out);

@@ -71,6 +71,8 @@ int msh_stark_verify_mssp(const msh_stark* h, const uint64_t* constrains, size_t
 /* FriProof (fri.rs:17-22) from its MSFP bytes: the compiled twin of the Rust shim's FriProof::from_msfp.  windows = rounds - 1; returns the
  * number of (window, query) records (windows * nq; the first `cap` are written to `out`) or -1 if the bytes do not parse exactly. */
 int msh_fri_proof_parse(const uint8_t* blob, size_t len, uint32_t e, uint32_t windows, uint32_t nq, msh_fri_query_view* out, size_t cap);
+/* synthetic trace of the build-defined degree-3 wide AIR (ms_mix_cubic): col_j[i+1] = col_j[i] col_{j+1}[i] col_{j+2}[i] + s_j col_{j+3}[i]; length x w row-major, w scalars */
+int msh_cubic_rows(uint64_t p, size_t length, size_t w, uint64_t seed, uint64_t* out, uint64_t* scalars);
 /* synthetic Fibonacci-AIR trace of the benchmark workload (N x 3 row-major) */
 int msh_fibonacci_rows(uint64_t p, size_t length, size_t steps, uint64_t secret_b, uint64_t pad_seed, uint64_t* out);
 #ifdef __cplusplus

@@ -210,8 +210,15 @@ class Context:
     def mix(self, r):
         return self.L.ms_mix(self.h, C.c_uint64(r))
 
+    def mix_cubic(self, r, spec, scalars):
+        """ms_mix_cubic (BUILD-DEFINED degree-3 composition with the true quotient; include/ministark.h): spec = [(j, a, b, c, d), ...]."""
+        sp = np.ascontiguousarray(spec, dtype=np.int32).reshape(-1, 5)
+        sc, scp = _u64(scalars)
+        return self.L.ms_mix_cubic(self.h, C.c_uint64(r), sp.ctypes.data_as(C.POINTER(C.c_int)), scp, C.c_int(len(sp)))
+
     def validity_read(self):
-        out = np.zeros(self.N, dtype=np.uint64)
+        self.L.ms_validity_len.restype = C.c_size_t
+        out = np.zeros(int(self.L.ms_validity_len(self.h)) or self.N, dtype=np.uint64)
         self.check(self.L.ms_validity_read(self.h, out.ctypes.data_as(_u64p)))
         return out
 

@@ -73,6 +73,8 @@ struct CtxBase {
   virtual int lde_commit(size_t blowup, u64 shift, size_t lpn, u8* root) = 0;
   virtual int lde_read(u64* out) = 0;
   virtual int mix(u64 r) = 0;
+  virtual int mix_cubic(u64 r, const int* spec, const u64* sc, int ncons) = 0;
+  virtual size_t validity_len_() const = 0;
   virtual int validity_read(u64* out) = 0;
   virtual int eval_ext(const u64* z, int q, u64* out) = 0;
   virtual int fri_begin(size_t blowup, size_t rounds, u8* root0) = 0;
@@ -849,7 +851,7 @@ template <class F> struct Ctx : CtxBase {
     if (ev_copy) msrt::event_destroy(ev_copy);
     if (copy_stream) msrt::stream_destroy(copy_stream);
     for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
-    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero, &d_lin};
+    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero, &d_lin, &d_cubic};
     for (DevBuf* b : bufs) b->release();
     if (pinned) msrt::free_host(pinned);
     if (own_stream) msrt::stream_destroy(own_stream);
@@ -1110,7 +1112,7 @@ template <class F> struct Ctx : CtxBase {
     const size_t c = (size_t)npolys;
     TreeShape ts;
     RQ(tree_shape(L_ * c, lpn, 2, &ts));
-    L = L_; blowup = blowup_; lde_c = c;
+    L = L_; blowup = blowup_; lde_c = c; lde_shift = shift;
     if (lpn == c && shardable(L_)) {  // one LDE row per leaf group: rank k evaluates and hashes the rows k (mod world)
       RQ(lde_compute_sharded(blowup_, shift));
       RQ((tree_build_sharded<1>(d_lde.as<T>(), L / (size_t)sh_world, 1, 0, (u32)c, ts, d_lde_nodes, lde_lin())));
@@ -1164,12 +1166,71 @@ template <class F> struct Ctx : CtxBase {
     RQ(ensure_polys(npolys + 1));
     typename mspoly::MixKernel<F>::Params p{d_polys.as<T>(), N, N, npolys, F::from_u64(r), d_polys.as<T>() + (size_t)npolys * N};
     CK(run<mspoly::MixKernel<F>>(K_MIX, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
-    have_validity = true; nrounds_done = 0;
+    have_validity = true; validity_len = N; nrounds_done = 0;
     return MS_OK;
+  }
+  // build-defined degree-3 composition with the true quotient (include/ministark.h; kernel: mspoly::CubicComposeKernel)
+  size_t validity_len = 0; u64 lde_shift = 0; DevBuf d_cubic;
+  size_t validity_len_() const override { return have_validity ? validity_len : 0; }
+  int mix_cubic(u64 r, const int* spec, const u64* sc, int ncons) override {
+    if (!have_lde) return fail(MS_ERR_STATE, "mix_cubic before lde_commit");
+    if (lde_ts.sharded) return fail(MS_ERR_STATE, "mix_cubic: the LDE of a sharded proof is distributed over the ranks");
+    if (!spec || !sc || ncons < 1 || ncons > 4096 || r >= F::P) return fail(MS_ERR_ARG, "mix_cubic arguments");
+    if (blowup < 4) return fail(MS_ERR_SHAPE, "mix_cubic needs blowup >= 4 (the quotient has 2N coefficients, the composition 3N)");
+    const size_t c = lde_c;
+    for (int t = 0; t < ncons; t++) { for (int u = 0; u < 5; u++) if (spec[5 * t + u] < 0 || (size_t)spec[5 * t + u] >= c) return fail(MS_ERR_ARG, "mix_cubic: polynomial index out of range"); if (sc[t] >= F::P) return fail(MS_ERR_ARG, "mix_cubic: scalar not canonical"); }
+    if (lde_cols_virtual) { RQ(lincomb_linear_columns(d_lde.as<T>(), lde_col_stride, lde_col_len)); lde_cols_virtual = false; }
+    typedef mspoly::CubicSpec<F> CS;
+    typedef mspoly::CubicComposeKernel<F> CK_;
+    const int logL = ctz64(L), logN = ctz64(N);
+    const T gL = f_root_of_unity<F>(logL), wN = f_root_of_unity<F>(logN), sh = F::from_u64(lde_shift);
+    // x^N - 1 on the coset: shift^N * zeta^(i mod blowup) - 1, zeta = g_L^N
+    const T shN = f_pow<F>(sh, (u64)N), zeta = f_pow<F>(gL, (u64)N);
+    std::vector<T> dinv(blowup);
+    { T z = F::from_u64(1);
+      for (size_t k = 0; k < blowup; k++) { const T den = F::sub(F::mul(shN, z), F::from_u64(1)); if (den == 0) return fail(MS_ERR_SHAPE, "mix_cubic: the LDE coset meets the trace domain (shift^N is a blowup-th root of unity)"); dinv[k] = f_inv<F>(den); z = F::mul(z, zeta); } }
+    std::vector<CS> hs(ncons);
+    { T rp = F::from_u64(1);
+      for (int t = 0; t < ncons; t++) { hs[t].j = (u32)spec[5 * t]; hs[t].a = (u32)spec[5 * t + 1]; hs[t].b = (u32)spec[5 * t + 2]; hs[t].c = (u32)spec[5 * t + 3]; hs[t].d = (u32)spec[5 * t + 4]; hs[t].s = F::from_u64(sc[t]); hs[t].rpow = rp; rp = F::mul(rp, F::from_u64(r)); } }
+    const size_t tab_bytes = hs.size() * sizeof(CS) + dinv.size() * sizeof(T);
+    if (d_cubic.ensure(2 * L * sizeof(T)) || d_tabs.ensure(tab_bytes + 64)) return fail(MS_ERR_NOMEM, "mix_cubic buffers");
+    CK(msrt::sync(stream));   // d_tabs may still be read by the previous proof's query phase; the host vectors below must outlive the copies
+    CK(msrt::h2d(d_tabs.p, hs.data(), hs.size() * sizeof(CS), stream));
+    CK(msrt::h2d(d_tabs.as<u8>() + hs.size() * sizeof(CS), dinv.data(), dinv.size() * sizeof(T), stream));
+    CK(msrt::sync(stream));
+    typename CK_::Params cp;
+    cp.lde = d_lde.as<T>(); cp.L = L; cp.blowup = (u32)blowup; cp.ncons = (u32)ncons; cp.spec = d_tabs.as<CS>();
+    cp.den_inv = reinterpret_cast<const T*>(d_tabs.as<u8>() + hs.size() * sizeof(CS));
+    cp.shift = sh; cp.gL = gL; cp.gL_step = f_pow<F>(gL, (u64)CK_::THREADS); cp.w_last = f_pow<F>(wN, (u64)(N - 1)); cp.out = d_cubic.as<T>();
+    CK(run<CK_>(K_MIX, grid1(L, CK_::THREADS * CK_::ITEMS), 1, CK_::THREADS, 0, cp));
+    // evaluations on shift * <g_L>  ->  coefficients of Q(shift y)  ->  q_k = coefficient_k * shift^-k
+    T* coef = d_cubic.as<T>() + L;
+    RQ(ntt_run(logL, true, d_cubic.as<T>(), L, L, coef, L, 1));
+    RQ(ensure_polys(npolys + 2));
+    // exactness: nothing above 2N coefficients (the reference's `assert_eq!(rest, zero)` of starks.rs:119, for the true quotient)
+    unsigned long long* dres;
+    RQ(degree_launch1(coef, L, &dres));
+    CK(msrt::d2h(pinned, dres, 8, stream));
+    CK(msrt::sync(stream));
+    if (*reinterpret_cast<unsigned long long*>(pinned) > 2 * N) return fail(MS_ERR_SHAPE, "mix_cubic: the constraints do not vanish on the trace domain (the quotient by x^N - 1 is not a polynomial of 2N coefficients)");
+    const T shi = f_inv<F>(sh);
+    typename msntt::ScalePowKernel<F>::Params sp;
+    sp.src = coef; sp.dst = d_polys.as<T>() + (size_t)npolys * N; sp.src_bstride = 0; sp.dst_bstride = 0; sp.n = 2 * N; sp.s = shi; sp.s_step = f_pow<F>(shi, msntt::ScalePowKernel<F>::THREADS);
+    CK(run<msntt::ScalePowKernel<F>>(K_SCALE_POW, grid1(2 * N, msntt::ScalePowKernel<F>::THREADS * msntt::ScalePowKernel<F>::ITEMS), 1, msntt::ScalePowKernel<F>::THREADS, 0, sp));
+    have_validity = true; validity_len = 2 * N; nrounds_done = 0;
+    return MS_OK;
+  }
+  int degree_launch1(const T* poly, size_t n, unsigned long long** dres_out) {   // trimmed length of a base-field coefficient vector
+    void* zr;
+    RQ(zero_alloc(8, &zr));
+    typename mspoly::DegreeKernel<F, 1>::Params dp{poly, 0, n, reinterpret_cast<unsigned long long*>(zr)};
+    CK(run<mspoly::DegreeKernel<F, 1>>(K_DEGREE, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
+    *dres_out = reinterpret_cast<unsigned long long*>(zr);
+    return 0;
   }
   int validity_read(u64* out) override {
     if (!have_validity || !out) return fail(MS_ERR_STATE, "validity_read");
-    return download_widen(d_polys.as<T>() + (size_t)npolys * N, N, 0, 1, out);
+    return download_widen(d_polys.as<T>() + (size_t)npolys * N, validity_len, 0, 1, out);
   }
 
   // evaluate `npoly` polynomials (views) at ext point z into dst as [npoly][E] T
@@ -1217,7 +1278,7 @@ template <class F> struct Ctx : CtxBase {
       for (int i0 = 0; i0 < np; i0 += mspoly::MAX_POLYS) {
         const int nb = (np - i0 < mspoly::MAX_POLYS) ? np - i0 : mspoly::MAX_POLYS;
         size_t off[mspoly::MAX_POLYS], cnt[mspoly::MAX_POLYS];
-        for (int i = 0; i < nb; i++) { off[i] = 0; cnt[i] = N; }
+        for (int i = 0; i < nb; i++) { off[i] = 0; cnt[i] = (i0 + i == npolys) ? validity_len : N; }   // the validity polynomial has 2N coefficients after ms_mix_cubic
         RQ((eval_views<1>(d_polys.as<T>() + (size_t)i0 * N, N, 0, 1, off, cnt, nb, zz, reinterpret_cast<T*>(pinned) + ((size_t)t * np + i0) * E)));   // results land in page-locked host memory
       }
     }
@@ -1316,13 +1377,14 @@ template <class F> struct Ctx : CtxBase {
     nrounds_done = 0; have_deep = false; blob_size = 0;
     fri_rounds = nrounds; fri_blowup = blowup_;
     Round* r = round_slot(0);
-    r->cap = N;
-    if (r->poly.ensure(N * E * sizeof(T))) return fail(MS_ERR_NOMEM, "round poly");
+    const size_t VL = validity_len;   // N (ms_mix) or 2N (ms_mix_cubic)
+    r->cap = VL;
+    if (r->poly.ensure(VL * E * sizeof(T))) return fail(MS_ERR_NOMEM, "round poly");
     // field.rs:23-32 extend_poly: limb 0 = validity, higher limbs zero
-    CK(msrt::memset_dev(r->poly.p, 0, N * E * sizeof(T), stream));
-    CK(msrt::d2d(r->poly.p, d_polys.as<T>() + (size_t)npolys * N, N * sizeof(T), stream));
+    CK(msrt::memset_dev(r->poly.p, 0, VL * E * sizeof(T), stream));
+    CK(msrt::d2d(r->poly.p, d_polys.as<T>() + (size_t)npolys * N, VL * sizeof(T), stream));
     size_t nc;
-    RQ(read_degree_and_root(r->poly.template as<T>(), r->cap, N, nullptr, &nc, nullptr));
+    RQ(read_degree_and_root(r->poly.template as<T>(), r->cap, VL, nullptr, &nc, nullptr));
     r->ncoef = nc;
     const size_t deg = nc ? nc - 1 : 0;
     size_t dsize = (deg + 1) * blowup_;  // fri.rs:74 (quirk Q11)
@@ -1874,6 +1936,8 @@ int ms_lde_commit(ms_ctx* ctx, size_t blowup, uint64_t shift, size_t lpn, uint8_
 int ms_lde_read(ms_ctx* ctx, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->lde_read(out); }
 int ms_mix(ms_ctx* ctx, uint64_t r) { CTX_OR_FAIL; return B(ctx)->mix(r); }
 int ms_validity_read(ms_ctx* ctx, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->validity_read(out); }
+int ms_mix_cubic(ms_ctx* ctx, uint64_t r, const int* spec, const uint64_t* s, int ncons) { CTX_OR_FAIL; return B(ctx)->mix_cubic(r, spec, s, ncons); }
+size_t ms_validity_len(const ms_ctx* ctx) { return ctx ? B(ctx)->validity_len_() : 0; }
 int ms_eval_ext(ms_ctx* ctx, const uint64_t* z, int q, uint64_t* out) { CTX_OR_FAIL; return B(ctx)->eval_ext(z, q, out); }
 int ms_fri_begin(ms_ctx* ctx, size_t blowup, size_t rounds, uint8_t root0[32]) { CTX_OR_FAIL; return B(ctx)->fri_begin(blowup, rounds, root0); }
 int ms_fri_deep(ms_ctx* ctx, const uint64_t* z, uint64_t* Bv) { CTX_OR_FAIL; return B(ctx)->fri_deep(z, Bv); }

@@ -591,6 +591,39 @@ template <class F, int E> struct QueryPointsKernel {
 };
 
 
+// ---------------------------------------------------------------- build-defined degree-3 composition (ms_mix_cubic)
+// BASELINE configs[4] names "degree-3 constraints", which the reference cannot express (quirk Q1: its `validity` polynomial is the REMAINDER of the division by
+// the vanishing polynomial, so any constraint polynomial with >= N coefficients panics).  The build-defined variant, with the TRUE quotient:
+//   C_t(x)      = P_j(w x) - P_a(x) P_b(x) P_c(x) - s P_d(x)            transition constraint t = (j, a, b, c, d, s); w = the trace domain's generator
+//   validity(x) = (sum_t r^t C_t(x)) (x - w^(N-1)) / (x^N - 1)           exact when every C_t vanishes on rows 0 .. N-2; 2N coefficients
+// evaluated pointwise on the committed LDE domain x_i = shift g_L^i (column-major LDE, P(w x_i) = the value `blowup` rows further on); x^N - 1 takes only
+// `blowup` distinct values there, whose inverses come in a table.  The caller interpolates (size-L INTT) and un-shifts.
+template <class F> struct CubicSpec { u32 j, a, b, c, d; typename F::T s, rpow; };
+template <class F> struct CubicComposeKernel {
+  typedef typename F::T T;
+  static constexpr int THREADS = mspoly::THREADS;
+  static constexpr int ITEMS = 8;
+  struct Params { const T* lde; size_t L; u32 blowup, ncons; const CubicSpec<F>* spec; const T* den_inv; T shift, gL, gL_step /* gL^THREADS */, w_last /* w^(N-1) */; T* out; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int, unsigned char*) {
+    size_t i = (size_t)bx * (THREADS * ITEMS) + tid;
+    if (i >= p.L) return;
+    T x = F::mul(p.shift, f_pow<F>(p.gL, i));
+    for (int it = 0; it < ITEMS && i < p.L; it++, i += THREADS) {
+      const size_t in = i + p.blowup < p.L ? i + p.blowup : i + p.blowup - p.L;   // w x_i = x_(i + blowup)
+      T acc = 0;
+      for (u32 t = 0; t < p.ncons; t++) {
+        const CubicSpec<F> c = p.spec[t];
+        T v = F::mul(F::mul(p.lde[(size_t)c.a * p.L + i], p.lde[(size_t)c.b * p.L + i]), p.lde[(size_t)c.c * p.L + i]);
+        v = F::add(v, F::mul(c.s, p.lde[(size_t)c.d * p.L + i]));
+        acc = F::add(acc, F::mul(c.rpow, F::sub(p.lde[(size_t)c.j * p.L + in], v)));
+      }
+      p.out[i] = F::mul(F::mul(acc, F::sub(x, p.w_last)), p.den_inv[i % p.blowup]);
+      x = F::mul(x, p.gL_step);
+    }
+  }
+};
+
 // ms_arith_selftest: one operation of the NTT tiles' arithmetic class per element (A = GLM for Goldilocks: inline asm with hand-managed
 // gfx950 wait states, which only a run on the device can check; BB for BabyBear).  Ops: include/ministark.h.
 template <int S> struct ArithShift { template <class A> static MS_DEV u64 run(u64 x, int s) { return s == S ? msntt::gl_mul_pow2<S, A>(x) : ArithShift<S - 1>::template run<A>(x, s); } };

@@ -34,6 +34,9 @@ def _host():
         path = host_library_path()
         if not os.path.exists(path):
             raise MsError(-6, f"{path} not found: run __graft_entry__.build()")
+        from . import _native
+        if not _native._LIBS:      # the mirror resolves ms_* against the libministark build loaded before it: the product's own, unless a test loaded the emulation build
+            _native.load_library()
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)
         L.msh_stark_new.restype = C.c_void_p
         for n in ("msh_proof_arthur", "msh_proof_evals", "msh_proof_fri_roots", "msh_proof_fri_blob", "msh_proof_challenges", "msh_proof_num_polys", "msh_proof_serialize",
@@ -196,3 +199,13 @@ def fibonacci_rows_native(p, length, steps, secret_b=2, pad_seed=0x5EED):
     if rc != 0:
         raise MsError(rc, "msh_fibonacci_rows")
     return out
+
+
+def cubic_rows_native(p, length, w, seed=9):
+    """msh_cubic_rows: the synthetic trace of the build-defined degree-3 wide AIR (same values as tests/parity_cases.py:cubic_trace) and its w scalars."""
+    out = np.empty((length, w), dtype=np.uint64)
+    sc = np.empty(w, dtype=np.uint64)
+    rc = _host().msh_cubic_rows(C.c_uint64(p), C.c_size_t(length), C.c_size_t(w), C.c_uint64(seed), out.ctypes.data_as(C.POINTER(C.c_uint64)), sc.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc != 0:
+        raise MsError(rc, "msh_cubic_rows")
+    return out, sc

@@ -558,6 +558,21 @@ int msh_fri_proof_parse(const u8* blob, size_t len, u32 e, u32 windows, u32 nq, 
     }
   return left == 0 ? (int)n : -1;
 }
+// synthetic trace of the build-defined degree-3 wide AIR (ms_mix_cubic; BASELINE configs[4]): row 0 and the w scalars from SplitMix64(seed), then
+// col_j[i+1] = col_j[i] * col_{j+1}[i] * col_{j+2}[i] + s_j * col_{j+3}[i]  (column indices mod w) - the same values as tests/parity_cases.py:cubic_trace
+int msh_cubic_rows(u64 p, size_t length, size_t w, u64 seed, u64* out, u64* scalars) {
+  if (!out || !scalars || !length || w < 4 || p < 2) return -1;
+  u64 sm = seed;
+  auto next = [&]() { sm += 0x9E3779B97F4A7C15ULL; u64 z = sm; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); };
+  auto mm = [&](u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % p); };
+  for (size_t j = 0; j < w; j++) scalars[j] = next() % p;
+  for (size_t j = 0; j < w; j++) out[j] = next() % p;
+  for (size_t i = 1; i < length; i++) {
+    const u64* a = out + (i - 1) * w; u64* b = out + i * w;
+    for (size_t j = 0; j < w; j++) b[j] = (u64)(((unsigned __int128)mm(mm(a[j], a[(j + 1) % w]), a[(j + 2) % w]) + mm(scalars[j], a[(j + 3) % w])) % p);
+  }
+  return 0;
+}
 // the synthetic Fibonacci-AIR trace of the benchmark workload (tests/e2e_goldilocks.rs:20-63 rows + SplitMix64 padding; = mini_stark_amd.synthetic.fibonacci_rows)
 int msh_fibonacci_rows(u64 p, size_t length, size_t steps, u64 secret_b, u64 pad_seed, u64* out) {
   if (!out || steps > length || p < 2) return -1;

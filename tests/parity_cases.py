@@ -8,6 +8,7 @@ import numpy as np
 
 from common import MODULUS, EXT, SplitMix64, fibonacci_trace, fibonacci_trace_fast, fibonacci_closures
 from oracle import oracle as orc
+ERR_SHAPE = -1
 
 
 def rand_field(field, shape, seed):
@@ -420,3 +421,110 @@ def case_arith_selftest(mk, field, nrand=1 << 16):
         want = np.array([(x << s_) % p for x, s_ in zip(aa, ss)], dtype=np.uint64)
         assert (got == want).all()
     assert ctx.L.ms_arith_selftest(ctx.h, 9, None, None, None, 0) != 0
+
+
+def cubic_trace(field, N, w, seed=9):
+    """A trace that satisfies the build-defined degree-3 transitions col_j[i+1] = col_j[i] * col_{j+1}[i] * col_{j+2}[i] + s_j * col_{j+3}[i] (indices mod w) on rows
+    0 .. N-2: random first row, the recurrence below it."""
+    p = MODULUS[field]
+    rng = SplitMix64(seed)
+    sc = [rng.field(p) for _ in range(w)]
+    rows = [[rng.field(p) for _ in range(w)]]
+    for _ in range(N - 1):
+        prev = rows[-1]
+        rows.append([(prev[j] * prev[(j + 1) % w] * prev[(j + 2) % w] + sc[j] * prev[(j + 3) % w]) % p for j in range(w)])
+    spec = [(j, j, (j + 1) % w, (j + 2) % w, (j + 3) % w) for j in range(w)]
+    return np.array(rows, dtype=np.uint64), spec, sc
+
+
+def case_mix_cubic(mk, field, log_n=4, w=4, blowup=8, seed=9):
+    """ms_mix_cubic (BASELINE configs[4]'s "degree-3 constraints", build-defined: the reference cannot express them) against a big-integer restatement by
+    the DEFINITION: C_t(x) = P_j(w x) - P_a P_b P_c - s P_d with schoolbook products, validity = (sum r^t C_t)(x - w^(N-1)) / (x^N - 1) by long division
+    (exact), 2N coefficients; then the DEEP-ALI identity validity(z) (z^N - 1) = (z - w^(N-1)) sum r^t C_t(z) from ms_eval_ext's values at an extension
+    point z and at w z; a full FRI over the 2N-coefficient validity polynomial (proof accepted by the verifier restatement's FRI part); and a trace with one
+    violated row must be refused (MS_ERR_SHAPE)."""
+    p, e = MODULUS[field], EXT[field]
+    N = 1 << log_n
+    trace, spec, sc = cubic_trace(field, N, w, seed)
+    ctx = mk(field)
+    rng = SplitMix64(seed + 1)
+    omega = orc.root_of_unity(field, N)
+    rc, _ = ctx.trace_commit(trace, w)
+    assert rc == 0, ctx.last_error()
+    assert ctx.interpolate() == 0
+    polys = [[int(v) for v in ctx.poly_read(j)] for j in range(w)]
+    shift = rng.nonzero(p)
+    rc, _ = ctx.lde_commit(blowup, shift, w)
+    assert rc == 0, ctx.last_error()
+    r = rng.field(p)
+    assert ctx.mix_cubic(r, spec, sc) == 0, ctx.last_error()
+    got = [int(v) for v in ctx.validity_read()]
+    assert len(got) == 2 * N
+
+    # ---- the definition, in Python integers
+    def pmul(a, b):
+        out = [0] * (len(a) + len(b) - 1)
+        for i, x in enumerate(a):
+            if x:
+                for k, y in enumerate(b):
+                    out[i + k] = (out[i + k] + x * y) % p
+        return out
+
+    def padd(a, b, sb=1):
+        n = max(len(a), len(b))
+        return [((a[i] if i < len(a) else 0) + sb * (b[i] if i < len(b) else 0)) % p for i in range(n)]
+    mixed, rp = [0], 1
+    for (j, a, b, c_, d), s_ in zip(spec, sc):
+        shifted = [polys[j][k] * pow(omega, k, p) % p for k in range(N)]            # P_j(w x)
+        C_t = padd(padd(shifted, pmul(pmul(polys[a], polys[b]), polys[c_]), -1), [s_ * v % p for v in polys[d]], -1)
+        mixed = padd(mixed, [rp * v % p for v in C_t])
+        rp = rp * r % p
+    num = pmul(mixed, [(-pow(omega, N - 1, p)) % p, 1])
+    quo = [0] * max(1, len(num) - N)
+    rem = list(num)
+    for k in range(len(num) - 1, N - 1, -1):                                         # divide by x^N - 1
+        q = rem[k]
+        quo[k - N] = q
+        rem[k] = 0
+        rem[k - N] = (rem[k - N] + q) % p
+    assert not any(rem), "the restatement's own division must be exact for a valid trace"
+    want = (quo + [0] * (2 * N))[:2 * N]
+    assert got == want
+    # ---- DEEP-ALI identity at an out-of-domain extension point (values at z and at w z)
+    from pyref import Tower
+    T = Tower(field, e)
+    z = tuple(rng.field(p) for _ in range(e))
+    wz = T.mul(z, T.from_base(omega))
+    rc, ev = ctx.eval_ext(np.array([z, wz], dtype=np.uint64))
+    assert rc == 0
+    E_ = lambda v: tuple(int(x) for x in v)
+    Pz, Pwz, Vz = [E_(ev[0][j]) for j in range(w)], [E_(ev[1][j]) for j in range(w)], E_(ev[0][w])
+    acc, rp = T.zero(), 1
+    for (j, a, b, c_, d), s_ in zip(spec, sc):
+        C_t = T.sub(T.sub(Pwz[j], T.mul(T.mul(Pz[a], Pz[b]), Pz[c_])), T.mul(Pz[d], T.from_base(s_)))
+        acc = T.add(acc, T.mul(C_t, T.from_base(rp)))
+        rp = rp * r % p
+    assert T.mul(Vz, T.sub(T.pow(z, N), T.one())) == T.mul(acc, T.sub(z, T.from_base(pow(omega, N - 1, p))))
+    # ---- FRI over the 2N-coefficient validity polynomial: commit phase + query phase run, round 0 has (2N - 1 trimmed) * blowup leaves
+    rounds = (2 * N * blowup).bit_length() - 1
+    rc, _root0 = ctx.fri_begin(blowup, rounds)
+    assert rc == 0, ctx.last_error()
+    nc0, D0 = ctx.fri_round_info(0)
+    assert nc0 <= 2 * N and D0 == 2 * N * blowup
+    for i in range(1, rounds):
+        rc, _B = ctx.fri_deep([rng.field(p) for _ in range(e)])
+        assert rc == 0
+        rc, _root = ctx.fri_fold_commit([rng.field(p) for _ in range(e)])
+        assert rc == 0, ctx.last_error()
+    rc, proof = ctx.fri_query([rng.next(), 5])
+    assert rc == 0 and len(proof) > 0
+    # ---- a violated row is refused, like the reference's assert on the first output of divide_by_vanishing_poly (starks.rs:119)
+    bad = trace.copy()
+    bad[N // 2, 0] = (int(bad[N // 2, 0]) + 1) % p
+    ctx2 = mk(field, fresh=True) if "fresh" in mk.__code__.co_varnames else mk(field)
+    assert ctx2.trace_commit(bad, w)[0] == 0 and ctx2.interpolate() == 0 and ctx2.lde_commit(blowup, shift, w)[0] == 0
+    assert ctx2.mix_cubic(r, spec, sc) == ERR_SHAPE
+    # blowup 2 cannot hold the 3N-coefficient composition
+    ctx3 = mk(field, fresh=True) if "fresh" in mk.__code__.co_varnames else mk(field)
+    assert ctx3.trace_commit(trace, w)[0] == 0 and ctx3.interpolate() == 0 and ctx3.lde_commit(2, shift, w)[0] == 0
+    assert ctx3.mix_cubic(r, spec, sc) == ERR_SHAPE
