@@ -234,6 +234,32 @@ template <class F> struct Ctx : CtxBase {
     }
     if (!rc && (msrt::d2h(g, b.p, sizeof g, stream) || msrt::sync(stream))) rc = fail(MS_ERR_HIP, "selftest download");
     if (!rc) for (int i = 0; i < 48; i++) if (g[i] != h[i]) { rc = fail(MS_ERR_HIP, "RCCL self test: payload mismatch"); break; }
+    // the choreography of a sliced digest exchange (exchange_slice): payload produced on the prover's stream, grouped send / recv on a SECOND stream behind an
+    // event, the prover's stream waiting for the exchange's event before it reads the result
+    if (!rc) {
+      msrt::Stream* cs = nullptr; msrt::Event* e1 = nullptr; msrt::Event* e2 = nullptr;
+      u64 h2[32], g2[32];
+      for (int i = 0; i < 32; i++) h2[i] = 0xA5A5A5A5DEADBEEFull + (u64)i * 0x1000193ull;
+      int er = msrt::stream_create(&cs) || msrt::event_create(&e1) || msrt::event_create(&e2);
+      if (!er) er = msrt::h2d(a.as<u8>() + 1024, h2, sizeof h2, stream) || msrt::memset_dev(b.as<u8>() + 1024, 0, sizeof h2, stream);
+      if (!er) er = msrt::event_record(e1, stream) || msrt::stream_wait_event(cs, e1);
+      if (!er) {
+        e = R.group_start();
+        if (!e) e = R.send(a.as<u8>() + 1024, 128, 1, 0, comm, cs);
+        if (!e) e = R.recv(b.as<u8>() + 1024, 128, 1, 0, comm, cs);
+        if (!e) e = R.send(a.as<u8>() + 1024 + 128, 128, 1, 0, comm, cs);     // a second, strided piece in the same group, as a slice of several peers' chunks would be
+        if (!e) e = R.recv(b.as<u8>() + 1024 + 128, 128, 1, 0, comm, cs);
+        const int e3 = R.group_end(); if (!e) e = e3;
+        er = e;
+      }
+      if (!er) er = msrt::event_record(e2, cs) || msrt::stream_wait_event(stream, e2);
+      if (!er) er = msrt::d2h(g2, b.as<u8>() + 1024, sizeof g2, stream) || msrt::sync(stream);
+      if (er) rc = fail(MS_ERR_HIP, "RCCL self test: exchange on the communication stream failed");
+      else for (int i = 0; i < 32; i++) if (g2[i] != h2[i]) { rc = fail(MS_ERR_HIP, "RCCL self test: payload mismatch on the communication stream"); break; }
+      if (cs) { msrt::sync(cs); msrt::stream_destroy(cs); }
+      if (e1) msrt::event_destroy(e1);
+      if (e2) msrt::event_destroy(e2);
+    }
     if (!rc && (msrt::d2h(g, a.p, sizeof g, stream) || msrt::sync(stream))) rc = fail(MS_ERR_HIP, "selftest download");
     if (!rc) for (int i = 0; i < 64; i++) if (g[i] != h[i]) { rc = fail(MS_ERR_HIP, "RCCL self test: all-reduce changed a one-rank payload"); break; }
     msrt::sync(stream);
