@@ -1402,6 +1402,7 @@ template <class F> struct Ctx : CtxBase {
     if (!root0 || nrounds < 1 || !blowup_) return fail(MS_ERR_ARG, "fri_begin");
     nrounds_done = 0; have_deep = false; blob_size = 0;
     fri_rounds = nrounds; fri_blowup = blowup_;
+    if (d_deg.p) CK(msrt::memset_dev(d_deg.p, 0, 256, stream));   // the self-clearing degree word of fri_fold_commit: zero again even if an earlier proof was abandoned mid-round
     Round* r = round_slot(0);
     const size_t VL = validity_len;   // N (ms_mix) or 2N (ms_mix_cubic)
     r->cap = VL;
