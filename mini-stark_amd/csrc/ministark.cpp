@@ -1281,9 +1281,10 @@ template <class F> struct Ctx : CtxBase {
       rp.partials = d_partials.as<T>(); rp.nblocks = nblocks; rp.per_thread = (nblocks + RK::THREADS - 1) / RK::THREADS; rp.npoly = npoly; rp.out = dst;
       XE zc = p.zpow2[8];  // z^256
       for (int i = 256; i < (int)chunk; i *= 2) zc = e_mul<F>(zc, zc);  // z^CH
-      rp.zc = zc;
-      XE zs = e_pow<F, E>(zc, rp.per_thread);
-      for (int i = 0; i < 8; i++) { rp.zs2[i] = zs; zs = e_mul<F>(zs, zs); }
+      XE zs = zc;
+      for (int i = 0; i < 8; i++) { rp.zs2[i] = zs; zs = e_mul<F>(zs, zs); }   // zc^(2^i)
+      rp.zc_step = zs;                                                          // zc^256 = zc^THREADS
+      static_assert(RK::THREADS == 256, "zc_step = zc^THREADS");
       CK(run_coop<RK>(K_EVAL_REDUCE, 1, RK::THREADS, RK::lds_bytes(), rp));
     }
     return 0;

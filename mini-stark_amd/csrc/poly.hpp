@@ -214,27 +214,30 @@ template <class F, int EC, int E> struct EvalKernel {
 template <class F, int E> struct ReducePartialsKernel {
   typedef typename F::T T;
   static constexpr int THREADS = mspoly::THREADS;
-  struct Params { const T* partials; size_t nblocks, per_thread /* S */; int npoly; Ext<F, E> zc; Ext<F, E> zs2[8]; T* out; };
+  // sum_b P_b zc^b with thread t taking the blocks b = t, t + THREADS, t + 2 THREADS, ...: neighbouring lanes read neighbouring partials and the loads of a
+  // thread do not depend on each other (r03: with a contiguous run of blocks per thread every iteration waited for its own uncoalesced load - 6.4 ms of the
+  // 66 ms of a 2^24-row proof sat in this one-workgroup kernel).  zc = z^CH; zs2[i] = zc^(2^i), i < 8; zc_step = zc^THREADS.
+  struct Params { const T* partials; size_t nblocks, per_thread /* ceil(nblocks / THREADS) */; int npoly; Ext<F, E> zc_step; Ext<F, E> zs2[8]; T* out; };
   static MS_HD size_t lds_bytes() { return (size_t)MAX_POLYS * E * (THREADS / 64) * sizeof(T); }
   static MS_DEV void run(const Params& p, int, int, int, int tid, unsigned char* lds) {   // cooperative: wave-shuffle block sum, as EvalKernel
     T* red = reinterpret_cast<T*>(lds);
     constexpr int WAVES = THREADS / 64;
     const int width = p.npoly * E;
-    const size_t b0 = (size_t)tid * p.per_thread;
     Ext<F, E> acc[MAX_POLYS];
     for (int i = 0; i < MAX_POLYS; i++) acc[i] = e_zero<F, E>();
-    if (b0 < p.nblocks) {
-      size_t b1 = b0 + p.per_thread; if (b1 > p.nblocks) b1 = p.nblocks;
-      for (size_t b = b1; b-- > b0;) {
+    if ((size_t)tid < p.nblocks) {
+      for (size_t j = p.per_thread; j-- > 0;) {   // Horner in zc^THREADS over this thread's blocks, last one first
+        const size_t b = (size_t)tid + j * THREADS;
+        const bool have = b < p.nblocks;
 #pragma unroll
         for (int i = 0; i < MAX_POLYS; i++) {
           if (i < p.npoly) {
-            Ext<F, E> v; for (int l = 0; l < E; l++) v.c[l] = p.partials[b * width + i * E + l];
-            acc[i] = e_add<F, E>(e_mul<F>(acc[i], p.zc), v);
+            Ext<F, E> v; for (int l = 0; l < E; l++) v.c[l] = have ? p.partials[b * width + i * E + l] : (T)0;
+            acc[i] = e_add<F, E>(e_mul<F>(acc[i], p.zc_step), v);
           }
         }
       }
-      Ext<F, E> sc = e_one<F, E>();
+      Ext<F, E> sc = e_one<F, E>();   // zc^tid
 #pragma unroll
       for (int i = 0; i < 8; i++) if ((tid >> i) & 1) sc = e_mul<F>(sc, p.zs2[i]);
 #pragma unroll
