@@ -660,6 +660,22 @@ template <class F> struct Ctx : CtxBase {
   // Counters that kernels bump (deferred-block lists, the degree result) must start at zero.  One memset clears a 256 KiB
   // pool; zero_alloc hands out fresh pieces of it and clears it again only when it runs out (stream order keeps earlier
   // users ahead of the clear) — a proof needs ~50 such counters, i.e. one memset instead of ~50 four-microsecond fills.
+  // page-locked staging for the per-proof job tables (r03): uploads out of it are plain DMA, not the runtime's pageable-memory path (which pins or stages the
+  // caller's pages on the fly), and need no synchronisation of their own - the area is rewritten by the NEXT proof's same stage, behind that stage's final
+  // stream synchronisation
+  void* h_tabs = nullptr; size_t h_tabs_cap = 0;
+  int tabs_host(size_t bytes, u8** out) {
+    if (bytes > h_tabs_cap) {
+      CK(msrt::sync(stream));                       // an upload out of the old area may still be in flight
+      if (h_tabs) msrt::free_host(h_tabs);
+      h_tabs = nullptr; h_tabs_cap = 0;
+      const size_t want = bytes + bytes / 4 + 4096;
+      if (msrt::malloc_host(&h_tabs, want)) { h_tabs = nullptr; return fail(MS_ERR_NOMEM, "page-locked table staging"); }
+      h_tabs_cap = want;
+    }
+    *out = reinterpret_cast<u8*>(h_tabs);
+    return 0;
+  }
   DevBuf d_zero; size_t zero_used = 0, zero_cap = 0;
   int zero_alloc(size_t bytes, void** out) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -880,6 +896,7 @@ template <class F> struct Ctx : CtxBase {
     DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero, &d_lin, &d_cubic};
     for (DevBuf* b : bufs) b->release();
     if (pinned) msrt::free_host(pinned);
+    if (h_tabs) msrt::free_host(h_tabs);
     if (own_stream) msrt::stream_destroy(own_stream);
   }
   int ext_degree() const override { return E; }
@@ -967,7 +984,7 @@ template <class F> struct Ctx : CtxBase {
     RQ(ensure_polys(npolys + 2));
     T* dst = d_polys.as<T>() + (size_t)npolys * N;
     CK(msrt::memset_dev(dst, 0, N * sizeof(T), stream));
-    if (n) RQ(upload_narrow(coeffs, n, dst));
+    if (n) { RQ(upload_narrow(coeffs, n, dst)); CK(msrt::sync(stream)); }   // the caller's buffer is only read during the call (include/ministark.h)
     poly_lin.push_back(Lin());
     npolys++; have_lde = have_validity = false;
     return MS_OK;
@@ -1220,10 +1237,11 @@ template <class F> struct Ctx : CtxBase {
       for (int t = 0; t < ncons; t++) { hs[t].j = (u32)spec[5 * t]; hs[t].a = (u32)spec[5 * t + 1]; hs[t].b = (u32)spec[5 * t + 2]; hs[t].c = (u32)spec[5 * t + 3]; hs[t].d = (u32)spec[5 * t + 4]; hs[t].s = F::from_u64(sc[t]); hs[t].rpow = rp; rp = F::mul(rp, F::from_u64(r)); } }
     const size_t tab_bytes = hs.size() * sizeof(CS) + dinv.size() * sizeof(T);
     if (d_cubic.ensure(2 * L * sizeof(T)) || d_tabs.ensure(tab_bytes + 64)) return fail(MS_ERR_NOMEM, "mix_cubic buffers");
-    CK(msrt::sync(stream));   // d_tabs may still be read by the previous proof's query phase; the host vectors below must outlive the copies
-    CK(msrt::h2d(d_tabs.p, hs.data(), hs.size() * sizeof(CS), stream));
-    CK(msrt::h2d(d_tabs.as<u8>() + hs.size() * sizeof(CS), dinv.data(), dinv.size() * sizeof(T), stream));
-    CK(msrt::sync(stream));
+    u8* ht;
+    RQ(tabs_host(tab_bytes + 64, &ht));     // (the previous user of the area, the last proof's query phase, ended with a stream synchronisation)
+    memcpy(ht, hs.data(), hs.size() * sizeof(CS));
+    memcpy(ht + hs.size() * sizeof(CS), dinv.data(), dinv.size() * sizeof(T));
+    CK(msrt::h2d(d_tabs.p, ht, tab_bytes, stream));
     typename CK_::Params cp;
     cp.lde = d_lde.as<T>(); cp.L = L; cp.blowup = (u32)blowup; cp.ncons = (u32)ncons; cp.spec = d_tabs.as<CS>();
     cp.den_inv = reinterpret_cast<const T*>(d_tabs.as<u8>() + hs.size() * sizeof(CS));
@@ -1675,18 +1693,18 @@ template <class F> struct Ctx : CtxBase {
     const size_t off_rec = bytes; bytes += rec_off.size() * sizeof(size_t);
     const size_t off_ql = bytes; bytes += qlen.size() * 8;
     const size_t off_x1 = bytes; bytes += x1h.size() * sizeof(T);
-    std::vector<u8> tab(bytes + 8);
-    for (size_t k = 0; k < tables.size(); k++) memcpy(tab.data() + toff[k], tables[k].data(), tables[k].size() * sizeof(SHJ));
-    if (!fjobs.empty()) memcpy(tab.data() + off_f, fjobs.data(), fjobs.size() * sizeof(FJ));
-    if (!pjobs.empty()) memcpy(tab.data() + off_p, pjobs.data(), pjobs.size() * sizeof(PJ));
-    if (!sjobs.empty()) memcpy(tab.data() + off_sp, sjobs.data(), sjobs.size() * sizeof(SPJ));
-    if (!cjobs.empty()) memcpy(tab.data() + off_cj, cjobs.data(), cjobs.size() * sizeof(msmerkle::CopyJob));
-    if (!rec_off.empty()) memcpy(tab.data() + off_rec, rec_off.data(), rec_off.size() * sizeof(size_t));
-    memcpy(tab.data() + off_ql, qlen.data(), qlen.size() * 8);
-    memcpy(tab.data() + off_x1, x1h.data(), x1h.size() * sizeof(T));
-    if (d_tabs.ensure(tab.size())) return fail(MS_ERR_NOMEM, "query tables");
-    CK(msrt::h2d(d_tabs.p, tab.data(), tab.size(), stream));
-    CK(msrt::sync(stream));  // `tab` is pageable host memory: keep it alive until the copy is done
+    u8* tab;
+    RQ(tabs_host(bytes + 8, &tab));
+    for (size_t k = 0; k < tables.size(); k++) memcpy(tab + toff[k], tables[k].data(), tables[k].size() * sizeof(SHJ));
+    if (!fjobs.empty()) memcpy(tab + off_f, fjobs.data(), fjobs.size() * sizeof(FJ));
+    if (!pjobs.empty()) memcpy(tab + off_p, pjobs.data(), pjobs.size() * sizeof(PJ));
+    if (!sjobs.empty()) memcpy(tab + off_sp, sjobs.data(), sjobs.size() * sizeof(SPJ));
+    if (!cjobs.empty()) memcpy(tab + off_cj, cjobs.data(), cjobs.size() * sizeof(msmerkle::CopyJob));
+    if (!rec_off.empty()) memcpy(tab + off_rec, rec_off.data(), rec_off.size() * sizeof(size_t));
+    memcpy(tab + off_ql, qlen.data(), qlen.size() * 8);
+    memcpy(tab + off_x1, x1h.data(), x1h.size() * sizeof(T));
+    if (d_tabs.ensure(bytes + 8)) return fail(MS_ERR_NOMEM, "query tables");
+    CK(msrt::h2d(d_tabs.p, tab, bytes + 8, stream));   // page-locked source: no synchronisation here (this stage ends with one; the area is next written by the next proof)
     const u8* dt = d_tabs.as<u8>();
     // ---- launches
     for (size_t k = 0; k < tables.size(); k++) {

@@ -4,7 +4,10 @@ import csv, glob, json, collections, os, shutil, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 O = f"gpurun_out/prof_{R}"
 one = lambda pat: max(glob.glob(pat), key=os.path.getmtime)   # gpurun merges every call's output into the same tree: take the newest
-shutil.copy(one(O + "/stats/*/*kernel_stats.csv"), f"profiles/{R}_kernel_stats.csv")
+try:
+    shutil.copy(one(O + "/stats/*/*kernel_stats.csv"), f"profiles/{R}_kernel_stats.csv")
+except ValueError:
+    print("no 8-lane kernel-stats pass in this run (rocprofv3 crashed): profiles/%s_kernel_stats.csv left as it is" % R)
 shutil.copy(one(O + "/stats1/*/*kernel_stats.csv"), f"profiles/{R}_kernel_stats_inflight1.csv")
 bench = [json.loads(l) for l in open(O + "/bench_default.json") if l.startswith("{")][-1]
 KN = bench["roofline"]["kernel"].replace("msntt::", "")
