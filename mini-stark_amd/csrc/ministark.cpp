@@ -2011,6 +2011,9 @@ int ms_merkle_prove(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext
 int ms_ntt(ms_ctx* ctx, uint64_t* data, size_t n, size_t batch, int inverse) { CTX_OR_FAIL; return B(ctx)->ntt(data, n, batch, inverse); }
 int ms_coset_lde(ms_ctx* ctx, const uint64_t* c, size_t ncoef, size_t batch, uint64_t shift, uint64_t* out, size_t L) { CTX_OR_FAIL; return B(ctx)->coset_lde(c, ncoef, batch, shift, out, L); }
 int ms_bench_lde(ms_ctx* ctx, size_t blowup, uint64_t shift) { CTX_OR_FAIL; return B(ctx)->bench_lde(blowup, shift); }
+#ifdef MS_NTT_TS   // tools/ntt_phase_ts.py: not part of the ABI, not in the product build
+int ms_debug_ntt_ts(void* dptr) { return hipMemcpyToSymbol(HIP_SYMBOL(msntt::g_ms_ntt_ts), &dptr, sizeof dptr) == hipSuccess ? MS_OK : MS_ERR_HIP; }
+#endif
 int ms_arith_selftest(ms_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { CTX_OR_FAIL; return B(ctx)->arith_selftest(op, a, b, out, n); }
 int ms_profile_begin(ms_ctx* ctx) { CTX_OR_FAIL; return B(ctx)->profile_begin(); }
 int ms_profile_end(ms_ctx* ctx, char* json_out, size_t cap) { CTX_OR_FAIL; return B(ctx)->profile_end(json_out, cap); }

@@ -37,6 +37,16 @@
 
 namespace msntt {
 
+// -DMS_NTT_TS (tools/ntt_phase_ts.py only; never in the product build): wave 0 of every workgroup stamps the shader clock at the phase boundaries of its
+// first MS_NTT_TS_TILES work items into a buffer handed over by ms_debug_ntt_ts: [PM][workgroup][item][slot]
+#ifdef MS_NTT_TS
+constexpr int MS_NTT_TS_TILES = 16, MS_NTT_TS_SLOTS = 12;
+__device__ unsigned long long* g_ms_ntt_ts = nullptr;
+#define MS_TS(slot) do { if (tid == 0 && g_ms_ntt_ts && ts_item < MS_NTT_TS_TILES) g_ms_ntt_ts[(((size_t)PM * 1024 + (size_t)bx) * MS_NTT_TS_TILES + ts_item) * MS_NTT_TS_SLOTS + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MS_TS(slot) do { } while (0)
+#endif
+
 constexpr int TILE_LOG_C = 4;       // 16 columns per tile
 constexpr int MAX_LOG_R = 10;       // tile rows <= 1024
 constexpr int MAX_LOG_PAD = 3;      // zero-padding factor folded into the virtual first pass <= 8
@@ -614,6 +624,9 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     const size_t n = (size_t)1 << p.log_n, cs = n >> K, f0 = tile << LC;
     const int c0 = (tid % LPR) * VEC, rb = tid / LPR;
     const T* s0 = p.src + by * p.src_bstride + f0 + c0 + (size_t)rb * cs;
+#ifdef MS_NTT_ABL_HOTLOAD   // timing only: every item re-reads tile 0 (cache-resident): what the load latency / read pattern costs
+    s0 = p.src + c0 + (size_t)rb * cs;
+#endif
     if (PM == 1 || p.n_in >= n) {
 #pragma unroll
       for (int i = 0; i < SWEEPS; i++) rows[i] = *reinterpret_cast<const V16*>(s0 + (size_t)(i * RPS) * cs);
@@ -720,6 +733,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         }
       }
     };
+    [[maybe_unused]] int ts_item = -1;
     for (size_t it = first; it < lim; it += stride) {
     if constexpr (SHARE) {   // the tile's tables, once for all its batch entries (the previous tile's last readers are behind its end-of-tile barrier)
       const size_t f0t = (base_g + it) << LC;
@@ -730,6 +744,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
     for (u32 bi = 0; bi < nin; bi++) {
       slot_item(base_g + it, bi, &tl, &by);
       [[maybe_unused]] const bool new_tile = bi == 0;
+      ts_item++; MS_TS(0);
       const size_t f0 = tl << LC;
       const bool row_tw = PM != 0 && !p.last && (f0 >> p.log_Rp) != 0;
       // ---- load: the tile's inputs go to LDS (behind the virtual pass: times w_(r0 r)^(i1 * row)); the row twiddles of this tile
@@ -742,6 +757,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         }
 #pragma unroll
         for (int i = 0; i < SWEEPS; i++) *reinterpret_cast<V16*>(tile + tix(rb + i * RPS, c0)) = rows[i];
+        MS_TS(1);
       } else {
         // virtual r0-point pass (r0 = C, only the first n/r0 inputs non-zero): A_1[k2*r0 + i1] = w_n^(i1*k) x[k], k = k2 + nprime*row.
         // The k2 part of the twiddle rides on the store twiddle; here x[k] * w_(r0 r)^(i1 * row).  One lane per tile element.
@@ -750,6 +766,7 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
 #pragma unroll
         for (int j = 0; j < NS; j++) { const int row = tid + j * TH; if (row < R) tile[tix(row, 0)] = sv[j]; }
         msrt::wg_barrier();
+        MS_TS(1);
         if constexpr (MERGE && !SHARE) build_tb0(f0);
         if constexpr (!SHIFT1 && TH % C == 0 && (((TH >> LC) >> BL) & 3) == 0) {
           // a thread's elements are (row r0 + k * TH/C, column i1): the rows' swizzle term is the same for all k, so every address is base + k * constant
@@ -769,7 +786,9 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
           }
         }
       }
+      MS_TS(2);
       msrt::wg_barrier();
+      MS_TS(3);
       if constexpr (!SHARE) build_tables(f0, row_tw);   // (SHARE: built once per tile, ahead of its batch entries)
       if constexpr (STAGE) {   // the next item's coefficients: in flight during the sub-rounds and the store
         if (bi + 1 < nin) stage_issue(tl, (size_t)bi + 1);
@@ -780,7 +799,9 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         }
       }
       sub_items<0, 0, MERGE>(tid, tile, w);
+      MS_TS(4);
       msrt::wg_barrier();
+      MS_TS(5);
       if constexpr (SHIFT1) {
         if constexpr (MERGE) {   // ts[E1][E2][c] = fa[E1] * fb[E2][c] (fa | fb complete behind the barrier above; read in the store phase, behind the next one)
           if (row_tw && new_tile) {
@@ -795,7 +816,9 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
         }
         sub1_shift(tid, tile);
       } else if constexpr (MERGE && NSUB == 3) sub_items<1, 0, true>(tid, tile, tb1); else sub_items<1, 0>(tid, tile, w);
+      MS_TS(6);
       msrt::wg_barrier();
+      MS_TS(7);
       T* dst = p.dst + by * p.dst_bstride;
       if constexpr (FUSE_TAIL) {
         // ---- last sub-round + store, fused: item = (row group g of 2^BL rows, column piece cq); the rows of a group are the last digit
@@ -836,9 +859,15 @@ template <class F, class A, bool INV, int K, int LC, int TH, int NSUB, int MODE>
             }
           }
 #pragma unroll
+#ifdef MS_NTT_ABL_NOSTORE   // timing only: the stores are predicated on a value that does not occur
+          for (int e = 0; e < NE; e++) if (o[J][e][0] == (T)0x123456789abcdefull) *reinterpret_cast<V16*>(outb + cq + ((size_t)(inew0 | (e << (B0_ + B1_))) << p.log_Rp)) = o[J][e];
+#else
           for (int e = 0; e < NE; e++) *reinterpret_cast<V16*>(outb + cq + ((size_t)(inew0 | (e << (B0_ + B1_))) << p.log_Rp)) = o[J][e];
+#endif
         }
+        MS_TS(8);
         msrt::wg_barrier();     // the tile and the per-tile tables are free for the next work item
+        MS_TS(9);
         continue;
       }
       if constexpr (NSUB >= 3) { sub_items<2, 0>(tid, tile, w); msrt::wg_barrier(); }

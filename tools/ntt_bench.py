@@ -16,6 +16,7 @@ ap.add_argument("--field", type=int, default=0)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--tag", default="")
+ap.add_argument("--passes", action="store_true", help="also print the per-kernel times of one LDE (the library's HIP-event profiler, ms_profile_begin / _end)")
 ap.add_argument("--linear", type=int, default=0, help="1: let the LDE stage use the linear-provenance shortcut (3 NTTs + 3 lincombs); 0: six NTTs (kernel measurement)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -44,4 +45,15 @@ for lr in a.log_rows:
     alg = c * (N + L) * s
     print(json.dumps({"tag": a.tag, "linear_shortcut": a.linear, "log_rows": lr, "blowup": a.blowup, "field": a.field, "lde_ms": round(ms_per, 4), "alg_GBps": round(alg / ms_per / 1e6, 1),
                       "frac_of_8TBps": round(alg / ms_per / 1e6 / 8000, 4)}))
+    if a.passes:
+        import ctypes as C
+        buf = C.create_string_buffer(1 << 14)
+        with torch.cuda.stream(stream):
+            ctx.check(ctx.L.ms_profile_begin(ctx.h))
+            for _ in range(5):
+                ctx.check(ctx.bench_lde(a.blowup, 12345))
+            ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
+        prof = json.loads(buf.value.decode())
+        print(json.dumps({"tag": a.tag, "log_rows": lr, "field": a.field,
+                          "pass_us": {k.replace("msntt::PassKernel2", "P2"): round(v["ms"] / max(1, v["launches"]) * 1e3, 1) for k, v in prof["ntt_pass_variants"].items()}}))
     ctx.close()
