@@ -88,7 +88,13 @@ template <class F> struct LincombKernel {
     const size_t j = (size_t)bx * nthreads + tid;
     if (j >= p.n) return;
     T acc = 0;
-    for (int t = 0; t < p.k; t++) acc = F::add(acc, F::mul(p.s[t], p.polys[(size_t)p.idx[t] * p.stride + j]));
+    const T one = F::from_u64(1), minus_one = F::neg(one);
+    for (int t = 0; t < p.k; t++) {   // the scalars are uniform over the launch: +1 / -1 (most of an AIR's transition constraints) are scalar branches, not multiplications - same canonical values
+      const T v = p.polys[(size_t)p.idx[t] * p.stride + j];
+      if (p.s[t] == one) acc = F::add(acc, v);
+      else if (p.s[t] == minus_one) acc = F::sub(acc, v);
+      else acc = F::add(acc, F::mul(p.s[t], v));
+    }
     p.dst[j] = acc;
   }
 };
@@ -113,7 +119,11 @@ template <class F> struct LincombMultiKernel {
         T acc = 0;
 #pragma unroll
         for (int u = 0; u < LCM_SRC; u++)
-          if (u < p.nsrc && p.m[o][u] != 0) acc = F::add(acc, F::mul(p.m[o][u], v[u]));
+          if (u < p.nsrc && p.m[o][u] != 0) {
+            if (p.m[o][u] == F::from_u64(1)) acc = F::add(acc, v[u]);
+            else if (p.m[o][u] == F::neg(F::from_u64(1))) acc = F::sub(acc, v[u]);
+            else acc = F::add(acc, F::mul(p.m[o][u], v[u]));
+          }
         p.dst[o][j] = acc;
       }
     }
