@@ -146,6 +146,9 @@ class Lanes:
         from mini_stark_amd.host import HostStark
         self.ms, self.io, self.n, self.io_mode = ms, io, inflight, io_mode
         self.samples = [set() for _ in range(inflight)]
+        # lane i starts i ms after lane 0 (inside the timed region): proofs that start together stay in lock-step for tens of proofs - all lanes in the latency-bound late FRI
+        # rounds at the same time, then all in the LDE hashing - and a 20-step run measured 246 proofs/s that way against 256 with the stagger (profiles/r03_lane_stagger.log)
+        self.stagger_ms = float(os.environ.get("MS_BENCH_STAGGER_MS", "1"))
         steps = (1 << log_rows) - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
         self.ctxs = [ms.Context(field, device=device_index, lib_path=lib) for _ in range(inflight)]
         self.tts = [fibonacci_air(c, steps, secret_b=seed0 + i) for i, c in enumerate(self.ctxs)]
@@ -164,6 +167,8 @@ class Lanes:
 
     def _prove_n(self, i, n):
         ptr = None if self.io else self.d_traces[i].data_ptr()
+        if self.stagger_ms and self.n > 1:
+            time.sleep(i * self.stagger_ms * 1e-3)
         for k in range(n):
             # io, mode "into" (default): the query-phase kernels write the FRI proof straight into the mirror's page-locked slot (ms_fri_query_into) - it is
             # complete when prove returns, and EVERY proof is touched on the host (one word per page) before its slot is reused two proofs later.
@@ -375,7 +380,7 @@ def main():
         "dtype": "u64" if args.field == 0 else "u32", "data": "synthetic",
         "config": {"workload": f"Fibonacci AIR, {field_name}, 2^{args.log_rows} trace rows, blowup {args.blowup}, 20 security bits "
                                f"(w=3, c=6, rounds={cfg.rounds}, ood_queries={cfg.constrain_queries}, fri_queries={cfg.fri_queries}); a step = {C_IN} independent proofs in flight per GPU",
-                   "proofs_per_step_per_gpu": C_IN, "parallelism": f"replicas x{world} GPUs x {C_IN} in-flight proofs (no data-path collective)"},
+                   "proofs_per_step_per_gpu": C_IN, "parallelism": f"replicas x{world} GPUs x {C_IN} in-flight proofs (no data-path collective; the lanes of a GPU start {lanes.stagger_ms:g} ms apart, inside the timed region)"},
     }
 
     # ---- N > 1: the sharded proof of BASELINE configs[3] as a second leg.  It runs in a CHILD process per rank (this script in --mode shard,
