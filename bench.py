@@ -371,6 +371,9 @@ def main():
     # ---- headline leg: independent proofs on every rank
     lanes = Lanes(args.field, args.log_rows, args.blowup, max(1, args.inflight), local_rank, dev, seed0=2 + rank * max(1, args.inflight), lib=lib)
     cfg, C_IN = lanes.cfg, lanes.n
+    if os.environ.get("MS_BENCH_DUMP_MAPS"):   # diagnostics: the process's mappings once every library is loaded (names the address ranges of a native stack trace)
+        with open(os.environ["MS_BENCH_DUMP_MAPS"], "w") as f:
+            f.write(open("/proc/self/maps").read())
     elapsed = lanes.timed(grp, args.steps, args.warmup)
     final_roots = grp.all_gather_bytes(lanes.last[0].fri_roots[-1])  # every rank finished a proof (outside the timed region)
     assert len(final_roots) == world

@@ -68,6 +68,7 @@ extern "C" {
     pub fn ms_fri_proof_read(ctx: *mut ms_ctx, out: *mut u8) -> c_int;
     pub fn ms_fri_proof_read_async(ctx: *mut ms_ctx, out: *mut u8) -> c_int;
     pub fn ms_fri_proof_wait(ctx: *mut ms_ctx) -> c_int;
+    pub fn ms_io_engine(ctx: *const ms_ctx) -> c_int;
     // ---- Tree trait (src/merkle.rs:8-30) on its own
     pub fn ms_merkle_commit(ctx: *mut ms_ctx, leafs: *const u64, leaf_num: usize, ext: c_int, lpn: usize, ic: usize,
                             nodes_out: *mut u8, nodes_cap: usize, nnodes: *mut usize, root: *mut u8) -> c_int;

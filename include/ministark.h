@@ -170,6 +170,10 @@ int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out);
  * ms_fri_query orders itself behind the copy on the device.  One read-back in flight per context. */
 int ms_fri_proof_read_async(ms_ctx* ctx, uint8_t* out);
 int ms_fri_proof_wait(ms_ctx* ctx);
+/* how the last read-back of this context travelled: 1 = an SDMA copy engine through the HSA runtime (hsa_amd_memory_async_copy_on_engine, forced onto the engine:
+ * never a blit kernel; the default for ms_fri_proof_read_async when the HSA runtime binds), 0 = the HIP runtime's copy (hipMemcpyAsync; env MS_READBACK=hip, the
+ * blocking ms_fri_proof_read, or the fall-back when the engine refused the copy). */
+int ms_io_engine(const ms_ctx* ctx);
 /* ms_fri_query with the FriProof written WHERE IT IS READ: the query-phase kernels store the MSFP blob straight into `out` - page-locked
  * host memory from ms_pinned_alloc (mapped into the device's address space) or device memory - of `cap` bytes; no read-back copy.  The
  * blob is complete when the call returns.  *len receives the blob size; with cap smaller than that nothing is computed and MS_ERR_ARG is

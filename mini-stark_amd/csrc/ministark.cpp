@@ -88,6 +88,7 @@ struct CtxBase {
   virtual int fri_proof_read(u8* out) = 0;
   virtual int fri_proof_read_async(u8* out) = 0;
   virtual int fri_proof_wait() = 0;
+  virtual int io_engine() const = 0;
   virtual int merkle_commit(const u64* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, u8* nodes_out, size_t cap, size_t* nn, u8* root) = 0;
   virtual int merkle_prove(const u64* leafs, size_t leaf_num, int ext, size_t lpn, const u64* leaf, u8* out, size_t cap, size_t* len) = 0;
   virtual int ntt(u64* data, size_t n, size_t batch, int inverse) = 0;
@@ -867,6 +868,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_LDE_MULTI")) lde_multi = atoi(e);
     if (const char* e = getenv("MS_LDE_VIRTUAL")) lde_virtual = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
+    if (const char* e = getenv("MS_READBACK")) readback_sdma = !strcmp(e, "hip") ? 0 : (!strcmp(e, "sdma-all") ? 2 : 1);
     if (const char* e = getenv("MS_LEAF_LAZY_MIN")) leaf_lazy_min = atoi(e);
     if (const char* e = getenv("MS_TREE_TOP")) { int v = atoi(e); if (v >= 1 && v <= 65536) tree_top_parents = v; }
     if (const char* e = getenv("MS_NTT_FAST_MIN")) ntt_fast_min = atoi(e);
@@ -885,7 +887,9 @@ template <class F> struct Ctx : CtxBase {
   ~Ctx() {
     for (auto& kv : plans) { kv.second->tw_lo.release(); kv.second->tw_hi.release(); kv.second->vtw.release(); kv.second->w0.release(); for (auto& b : kv.second->w_r) b.release(); delete kv.second; }
     drop_rccl();
-    if (copy_pending) msrt::event_sync(ev_copy);
+    if (sdma_pending) msrt::Sdma::get().wait(sdma_sig, 20.0);
+    else if (copy_pending) msrt::event_sync(ev_copy);
+    if (sdma_state == 1) msrt::Sdma::get().signal_destroy(sdma_sig);
     for (msrt::Event* e : ev_hash) msrt::event_destroy(e);
     for (msrt::Event* e : ev_xchg) msrt::event_destroy(e);
     if (comm_stream) msrt::stream_destroy(comm_stream);
@@ -1610,7 +1614,7 @@ template <class F> struct Ctx : CtxBase {
     for (size_t i = 0; i <= W; i++) sh_elems += (size_t)nq * (sh_scratch_elems((rounds[i]->ncoef + 1) / 2) + sh_scratch_elems(rounds[i]->ncoef / 2));
     const size_t n_h0 = (W + 1) * nq * 2 * E, n_tg = (W ? W : 1) * 2 * nq * E;
     if (copy_pending && !ext_out) {   // an asynchronous read-back of the previous proof: finish it before the blob moves, order it before the blob is rewritten
-      if (pos + 8 > d_blob.cap) RQ(fri_proof_wait()); else CK(msrt::stream_wait_event(stream, ev_copy));
+      if (sdma_pending || pos + 8 > d_blob.cap) RQ(fri_proof_wait()); else CK(msrt::stream_wait_event(stream, ev_copy));   // (an SDMA copy is waited for on the host: it ended a whole proof ago)
     }
     if ((!ext_out && d_blob.ensure(pos + 8)) || d_sh.ensure(sh_elems * sizeof(T)) || d_targets.ensure((n_h0 + n_tg) * sizeof(T)) || d_idx.ensure((W ? W : 1) * nq * 2 * 8))
       return fail(MS_ERR_NOMEM, "query buffers");
@@ -1763,6 +1767,11 @@ template <class F> struct Ctx : CtxBase {
     if (!blob_size || !out) return fail(MS_ERR_STATE, "no FRI proof");
     if (blob_external) return fail(MS_ERR_STATE, "the FRI proof was written to the caller's buffer (ms_fri_query_into)");
     RQ(fri_proof_wait());
+    if (readback_sdma > 1 && sdma_ready() && msrt::is_pinned_host(out)) {   // MS_READBACK=sdma-all: the blocking read on the copy engine as well (page-locked destinations only)
+      RQ(fri_proof_read_async(out));
+      return fri_proof_wait();
+    }
+    last_io_engine = 0;
     CK(msrt::d2h(out, d_blob.p, blob_size, stream));
     CK(msrt::sync(stream));
     return MS_OK;
@@ -1770,9 +1779,33 @@ template <class F> struct Ctx : CtxBase {
   // The same copy on the context's COPY stream, ordered behind the query phase by an event: the call returns at once and the next proof's
   // stages run while the ~64 MiB travel; the next ms_fri_query waits (on the device, not on the host) for the copy before it rewrites the blob.
   msrt::Stream* copy_stream = nullptr; msrt::Event* ev_blob = nullptr; msrt::Event* ev_copy = nullptr; bool copy_pending = false;
+  // r04: the read-back as an explicit SDMA copy through the HSA runtime (rt.hpp, msrt::Sdma) - queued on a copy engine whatever the engines' load, never a
+  // blit kernel; completion is an HSA signal the host waits on (ms_fri_proof_wait, or the next ms_fri_query before it rewrites the blob).  MS_READBACK=hip keeps
+  // hipMemcpyAsync on the copy stream (A/B); io_engine() reports which path the last read-back took.
+  int readback_sdma = 1, sdma_gpu = -1, sdma_state = 0 /* 0 untried, 1 bound, 2 unavailable */, last_io_engine = 0;
+  msrt::Sdma::Signal sdma_sig{0}; bool sdma_pending = false;
+  bool sdma_ready() {
+    if (!readback_sdma) return false;
+    if (sdma_state == 0) {
+      sdma_state = 2;
+      msrt::Sdma& S = msrt::Sdma::get();
+      if (!S.bind_device(device, &sdma_gpu) && !S.signal_create(&sdma_sig)) sdma_state = 1;
+    }
+    return sdma_state == 1;
+  }
+  int io_engine() const override { return last_io_engine; }
   int fri_proof_read_async(u8* out) override {
     if (!blob_size || !out) return fail(MS_ERR_STATE, "no FRI proof");
     if (blob_external) return fail(MS_ERR_STATE, "the FRI proof was written to the caller's buffer (ms_fri_query_into)");
+    RQ(fri_proof_wait());   // one read-back in flight per context
+    if (sdma_ready() && msrt::is_pinned_host(out)) {     // ms_fri_query ended with a stream synchronisation: the blob is complete, the copy needs no dependency (the synchronisation here returns at once)
+      CK(msrt::sync(stream));
+      msrt::Sdma& S = msrt::Sdma::get();
+      const int e = S.copy_d2h(sdma_gpu, out, d_blob.p, blob_size, sdma_sig, S.d2h_engine(sdma_gpu));
+      if (!e) { sdma_pending = true; copy_pending = true; last_io_engine = 1; return MS_OK; }
+      sdma_state = 2;       // refused (engine id / access): this context stays on the runtime's copy from here on
+    }
+    last_io_engine = 0;
     if (!copy_stream) { CK(msrt::stream_create(&copy_stream)); CK(msrt::event_create(&ev_blob)); CK(msrt::event_create(&ev_copy)); }
     CK(msrt::event_record(ev_blob, stream));
     CK(msrt::stream_wait_event(copy_stream, ev_blob));
@@ -1782,6 +1815,11 @@ template <class F> struct Ctx : CtxBase {
     return MS_OK;
   }
   int fri_proof_wait() override {
+    if (sdma_pending) {
+      sdma_pending = false; copy_pending = false;
+      if (msrt::Sdma::get().wait(sdma_sig, 20.0)) return fail(MS_ERR_HIP, "SDMA read-back did not complete within 20 s");
+      return MS_OK;
+    }
     if (copy_pending) { CK(msrt::event_sync(ev_copy)); copy_pending = false; }
     return MS_OK;
   }
@@ -2002,6 +2040,7 @@ size_t ms_fri_proof_size(const ms_ctx* ctx) { return ctx ? B(ctx)->fri_proof_siz
 int ms_fri_proof_read(ms_ctx* ctx, uint8_t* out) { CTX_OR_FAIL; return B(ctx)->fri_proof_read(out); }
 int ms_fri_proof_read_async(ms_ctx* ctx, uint8_t* out) { CTX_OR_FAIL; return B(ctx)->fri_proof_read_async(out); }
 int ms_fri_proof_wait(ms_ctx* ctx) { CTX_OR_FAIL; return B(ctx)->fri_proof_wait(); }
+int ms_io_engine(const ms_ctx* ctx) { return ctx ? B(ctx)->io_engine() : MS_ERR_ARG; }
 int ms_merkle_commit(ms_ctx* ctx, const uint64_t* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, uint8_t* nodes_out, size_t cap, size_t* nn, uint8_t root[32]) {
   CTX_OR_FAIL; return B(ctx)->merkle_commit(leafs, leaf_num, ext, lpn, ic, nodes_out, cap, nn, root);
 }

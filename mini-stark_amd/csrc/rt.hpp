@@ -46,6 +46,7 @@ inline int event_record(Event*, Stream*) { return 0; }
 inline int event_elapsed_ms(float* ms, Event*, Event*) { *ms = 0.f; return 0; }
 inline int stream_wait_event(Stream*, Event*) { return 0; }
 inline int event_sync(Event*) { return 0; }
+inline bool is_pinned_host(const void*) { return false; }
 template <class K>
 inline int launch(Stream*, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
   std::vector<unsigned char> lds(lds_bytes + 16);
@@ -67,6 +68,18 @@ struct Rccl {
   const char* (*err_string)(int) = nullptr;
   static Rccl& get() { static Rccl r; return r; }
   int load() { return 1; }
+};
+// no copy engines in the emulation build: the read-back is the plain copy
+struct Sdma {
+  struct Signal { unsigned long long handle = 0; };
+  static Sdma& get() { static Sdma s; return s; }
+  int load() { return 1; }
+  int bind_device(int, int*) { return 1; }
+  int signal_create(Signal*) { return 1; }
+  void signal_destroy(Signal) {}
+  int copy_d2h(int, void*, const void*, size_t, Signal, unsigned) { return 1; }
+  int wait(Signal, double) { return 1; }
+  unsigned d2h_engine(int) { return 0; }
 };
 }  // namespace msrt
 // ---- cooperative kernels (K::run with workgroup barriers INSIDE the function, per-thread state alive across them): every thread of a
@@ -137,6 +150,8 @@ MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned
 #else  // ---------------------------------------------------------------- HIP (gfx950)
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <ctime>
+#include <vector>
 #define MS_HD __host__ __device__ __forceinline__
 #define MS_DEV __device__ __forceinline__
 #define MS_RESTRICT __restrict__
@@ -163,6 +178,12 @@ inline int event_record(Event* e, Stream* s) { return (int)hipEventRecord(e, s);
 inline int event_elapsed_ms(float* ms, Event* a, Event* b) { return (int)hipEventElapsedTime(ms, a, b); }
 inline int stream_wait_event(Stream* s, Event* e) { return (int)hipStreamWaitEvent(s, e, 0); }
 inline int event_sync(Event* e) { return (int)hipEventSynchronize(e); }
+// page-locked host memory the device can address (hipHostMalloc / hipHostRegister): the only kind of destination a copy engine may be pointed at directly
+inline bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable memory: "invalid value" - clear the sticky error
+  return a.type == hipMemoryTypeHost;
+}
 
 // ---- RCCL, bound at run time (dlopen: the library neither links against nor requires librccl unless ms_set_shard_rccl is used).
 // Only the handful of entry points the sharded proof needs; types restated from <rccl/rccl.h> (ncclUniqueId = 128 opaque bytes,
@@ -206,6 +227,119 @@ inline int Rccl::load() {
   lib = h;
   return 0;
 }
+
+}  // namespace msrt
+// ---- SDMA copies through the HSA runtime, bound at run time (the runtime HIP itself sits on: already mapped into the process).
+// hipMemcpyAsync(device -> page-locked host) leaves the choice between a copy engine and a shader blit kernel (`__amd_rocclr_copyBuffer`) to the runtime; with
+// eight provers in flight part of the 64 MiB read-backs ran as blit kernels that take issue slots from the VALU-bound provers (r02/r03 I/O legs).
+// hsa_amd_memory_async_copy_on_engine with force_copy_on_sdma queues the copy on a chosen SDMA engine; completion is an HSA signal the host waits on.
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <mutex>
+namespace msrt {
+struct Sdma {
+  typedef hsa_signal_t Signal;
+  void* lib = nullptr; int state = 0;   // 0 not tried, 1 ready, 2 unavailable
+  std::mutex mu;
+  decltype(&hsa_init) f_init = nullptr;
+  decltype(&hsa_iterate_agents) f_iterate = nullptr;
+  decltype(&hsa_agent_get_info) f_agent_info = nullptr;
+  decltype(&hsa_signal_create) f_sig_create = nullptr;
+  decltype(&hsa_signal_destroy) f_sig_destroy = nullptr;
+  decltype(&hsa_signal_store_relaxed) f_sig_store = nullptr;
+  decltype(&hsa_signal_wait_scacquire) f_sig_wait = nullptr;
+  decltype(&hsa_amd_memory_async_copy_on_engine) f_copy = nullptr;
+  decltype(&hsa_amd_memory_copy_engine_status) f_status = nullptr;
+  decltype(&hsa_amd_memory_get_preferred_copy_engine) f_pref = nullptr;
+  hsa_agent_t cpu{0}; bool have_cpu = false;
+  struct Gpu { hsa_agent_t agent; uint32_t bdf, domain; unsigned d2h_engine; };
+  std::vector<Gpu> gpus;
+  std::vector<int> dev_gpu;   // HIP device ordinal -> index into gpus (-1: not matched)
+  static Sdma& get() { static Sdma s; return s; }
+  static hsa_status_t agent_cb(hsa_agent_t a, void* self) {
+    Sdma* S = reinterpret_cast<Sdma*>(self);
+    hsa_device_type_t ty;
+    if (S->f_agent_info(a, HSA_AGENT_INFO_DEVICE, &ty) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (ty == HSA_DEVICE_TYPE_CPU) { if (!S->have_cpu) { S->cpu = a; S->have_cpu = true; } }
+    else if (ty == HSA_DEVICE_TYPE_GPU) {
+      Gpu g; g.agent = a; g.bdf = 0; g.domain = 0; g.d2h_engine = 0;
+      S->f_agent_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &g.bdf);
+      S->f_agent_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &g.domain);
+      S->gpus.push_back(g);
+    }
+    return HSA_STATUS_SUCCESS;
+  }
+  // 0 on success.  MS_HSA_LIB names the library (default: the HSA runtime already mapped into the process, else libhsa-runtime64.so.1)
+  int load() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (state) return state == 1 ? 0 : 1;
+    state = 2;
+    const char* names[] = {getenv("MS_HSA_LIB"), "libhsa-runtime64.so.1", "libhsa-runtime64.so", "/opt/rocm/lib/libhsa-runtime64.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { if (n && *n) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; } }   // the copy HIP initialised, not a second runtime
+    if (!h) for (const char* n : names) { if (n && *n) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; } }
+    if (!h) return 1;
+#define MS_HSA_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(h, name)); if (!field) return 1
+    MS_HSA_SYM(f_init, "hsa_init"); MS_HSA_SYM(f_iterate, "hsa_iterate_agents"); MS_HSA_SYM(f_agent_info, "hsa_agent_get_info");
+    MS_HSA_SYM(f_sig_create, "hsa_signal_create"); MS_HSA_SYM(f_sig_destroy, "hsa_signal_destroy"); MS_HSA_SYM(f_sig_store, "hsa_signal_store_relaxed");
+    MS_HSA_SYM(f_sig_wait, "hsa_signal_wait_scacquire"); MS_HSA_SYM(f_copy, "hsa_amd_memory_async_copy_on_engine"); MS_HSA_SYM(f_status, "hsa_amd_memory_copy_engine_status");
+#undef MS_HSA_SYM
+    f_pref = reinterpret_cast<decltype(f_pref)>(dlsym(h, "hsa_amd_memory_get_preferred_copy_engine"));   // optional (HSA AMD extension 1.8)
+    if (f_init() != HSA_STATUS_SUCCESS) return 1;            // reference-counted: HIP holds the runtime open already
+    if (f_iterate(&agent_cb, this) != HSA_STATUS_SUCCESS || !have_cpu || gpus.empty()) return 1;
+    lib = h; state = 1;
+    return 0;
+  }
+  // HIP device -> HSA agent by PCI address; *gpu_index identifies it in the calls below
+  int bind_device(int hip_device, int* gpu_index) {
+    if (load()) return 1;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)dev_gpu.size() <= hip_device) dev_gpu.resize(hip_device + 1, -2);
+    if (dev_gpu[hip_device] == -2) {
+      int dom = 0, bus = 0, dv = 0;
+      dev_gpu[hip_device] = -1;
+      if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, hip_device) == hipSuccess && hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_device) == hipSuccess &&
+          hipDeviceGetAttribute(&dv, hipDeviceAttributePciDeviceId, hip_device) == hipSuccess) {
+        for (size_t i = 0; i < gpus.size(); i++)
+          if (((gpus[i].bdf >> 8) & 0xFF) == (uint32_t)bus && ((gpus[i].bdf >> 3) & 0x1F) == (uint32_t)dv && gpus[i].domain == (uint32_t)dom) dev_gpu[hip_device] = (int)i;
+      }
+      if (dev_gpu[hip_device] < 0 && gpus.size() == 1) dev_gpu[hip_device] = 0;   // a single visible GPU needs no matching
+      if (dev_gpu[hip_device] >= 0) {
+        Gpu& g = gpus[dev_gpu[hip_device]];
+        uint32_t avail = 0, pref = 0;
+        if (const char* e = getenv("MS_SDMA_ENGINE")) g.d2h_engine = (unsigned)strtoul(e, nullptr, 0);      // an hsa_amd_sdma_engine_id_t bit
+        else {
+          f_status(cpu, g.agent, &avail);                                  // engines usable for device -> host (bits of hsa_amd_sdma_engine_id_t)
+          if (f_pref) f_pref(cpu, g.agent, &pref);
+          uint32_t m = (pref & avail) ? (pref & avail) : (avail ? avail : pref);
+          g.d2h_engine = m ? (m & (~m + 1)) : 0;                           // lowest set bit
+        }
+        if (!g.d2h_engine) dev_gpu[hip_device] = -1;
+      }
+    }
+    if (dev_gpu[hip_device] < 0) return 1;
+    *gpu_index = dev_gpu[hip_device];
+    return 0;
+  }
+  unsigned d2h_engine(int gpu_index) { return gpus[gpu_index].d2h_engine; }
+  int signal_create(Signal* s) { return f_sig_create(1, 0, nullptr, s) == HSA_STATUS_SUCCESS ? 0 : 1; }
+  void signal_destroy(Signal s) { if (s.handle) f_sig_destroy(s); }
+  // device memory of `gpu_index` -> page-locked host memory, on SDMA engine `engine`; `sig` reads 0 when the bytes have landed
+  int copy_d2h(int gpu_index, void* dst_host, const void* src_dev, size_t n, Signal sig, unsigned engine) {
+    f_sig_store(sig, 1);
+    return (int)f_copy(dst_host, cpu, src_dev, gpus[gpu_index].agent, n, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)engine, true);
+  }
+  // 0: complete; 1: not within `seconds`
+  int wait(Signal sig, double seconds) {
+    const uint64_t slice = 2000000000ull;   // the timeout is in ticks of the system timestamp counter (>= 1e8 Hz here): wake up now and then, bound the total by wall time
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+      if (f_sig_wait(sig, HSA_SIGNAL_CONDITION_LT, 1, slice, HSA_WAIT_STATE_BLOCKED) < 1) return 0;
+      timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > seconds) return 1;
+    }
+  }
+};
 
 // optional K::MIN_WAVES = minimum waves per SIMD the register allocator must leave room for
 template <class K, class = void> struct MinWaves { static constexpr int v = 1; };
