@@ -138,7 +138,7 @@ class Lanes:
     host-mirror Stark each.  io=False: traces resident in HBM, FRI proofs left in HBM.  io=True: every proof uploads its trace
     from page-locked host memory and reads the FRI proof back into page-locked host memory."""
 
-    def __init__(self, field, log_rows, blowup, inflight, device_index, dev, seed0=2, io=False, lib=None, io_mode="async"):
+    def __init__(self, field, log_rows, blowup, inflight, device_index, dev, seed0=2, io=False, lib=None, io_mode="async", upload=None):
         import numpy as np
         import torch
         import mini_stark_amd as ms
@@ -154,7 +154,8 @@ class Lanes:
         self.tts = [fibonacci_air(c, steps, secret_b=seed0 + i) for i, c in enumerate(self.ctxs)]
         self.cfg = StarkConfig(self.ctxs[0], 20, blowup, steps, self.tts[0].constrain_number())
         self.starks = [HostStark(c, 20, blowup, steps, self.tts[0].constrain_number()) for c in self.ctxs]
-        if io:
+        self.upload = io if upload is None else upload   # (tools/io_probe3.py splits the I/O leg into its upload and read-back halves)
+        if self.upload:
             self.pinned = [torch.from_numpy(t.data.view(np.int64)).pin_memory() for t in self.tts]
             for t, pt in zip(self.tts, self.pinned):   # prove_raw takes the host pointer from trace.data
                 t.data = pt.numpy().view(np.uint64)
@@ -166,7 +167,7 @@ class Lanes:
         self.last = [None] * inflight
 
     def _prove_n(self, i, n):
-        ptr = None if self.io else self.d_traces[i].data_ptr()
+        ptr = None if self.upload else self.d_traces[i].data_ptr()
         if self.stagger_ms and self.n > 1:
             time.sleep(i * self.stagger_ms * 1e-3)
         for k in range(n):

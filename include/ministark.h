@@ -87,7 +87,8 @@ void ms_pinned_free(void* p);
  * Commitments with fewer than MS_SHARD_MIN_LEAVES (env, default 32768) leaf groups stay replicated.
  * world must be a power of two; world = 1 switches sharding off.  ms_lde_read / ms_fri_round_codeword_read
  * are not available for sharded commitments (each rank holds its part only). */
-typedef enum { MS_XCHG_ALL_TO_ALL = 0, MS_XCHG_ALL_GATHER = 1, MS_XCHG_ALL_REDUCE_MIN_U64 = 2, MS_XCHG_ALL_REDUCE_SUM_U8 = 3, MS_XCHG_ALL_TO_ALL_SLICE = 4 } ms_xchg_op;
+typedef enum { MS_XCHG_ALL_TO_ALL = 0, MS_XCHG_ALL_GATHER = 1, MS_XCHG_ALL_REDUCE_MIN_U64 = 2, MS_XCHG_ALL_REDUCE_SUM_U8 = 3, MS_XCHG_ALL_TO_ALL_SLICE = 4,
+               MS_XCHG_GATHER = 5 } ms_xchg_op;
 typedef int (*ms_exchange_fn)(void* user, int op, size_t bytes);
 int ms_set_shard(ms_ctx* ctx, int rank, int world, void* d_send, void* d_recv, size_t cap_bytes, ms_exchange_fn fn, void* user);
 int ms_shard_slice_layout(ms_ctx* ctx, size_t* offset, size_t* stride);

@@ -360,6 +360,14 @@ template <class F> inline Ext<F, 2> e_inv(const Ext<F, 2>& a) {
   return r;
 }
 
+template <class F> inline Ext<F, 4> e_inv(const Ext<F, 4>& a) {   // (a0 + a1 v)^-1 = (a0 - a1 v) / (a0^2 - (u - 11) a1^2), v^2 = u - 11
+  const Ext<F, 2> a0{{a.c[0], a.c[1]}}, a1{{a.c[2], a.c[3]}};
+  const Ext<F, 2> di = e_inv<F>(e_sub<F, 2>(e_mul<F>(a0, a0), e_mul_nr4<F>(e_mul<F>(a1, a1))));
+  const Ext<F, 2> r0 = e_mul<F>(a0, di), r1 = e_mul<F>(a1, di);
+  Ext<F, 4> r; r.c[0] = r0.c[0]; r.c[1] = r0.c[1]; r.c[2] = F::neg(r1.c[0]); r.c[3] = F::neg(r1.c[1]);
+  return r;
+}
+
 // SoA view of a vector of extension elements: limb k of element j at p[k*limb_stride + off + j*stride]
 template <class F, int E> struct ExtView {
   typename F::T* p;

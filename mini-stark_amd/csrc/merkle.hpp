@@ -595,6 +595,38 @@ struct CopyJobsKernel {
     for (size_t i = (size_t)tid; i < j.bytes; i += (size_t)nthreads) j.dst[i] = j.src[i];
   }
 };
+// the same for LARGE ranges (the ranks' slices of a sharded proof's quotient polynomials, tens of MiB each): blockIdx.y = job, blockIdx.x = a 32 KiB piece of it;
+// sources, destinations and lengths are multiples of 8 bytes (u64 elements of the MSFP blob)
+struct CopyRangesKernel {
+  static constexpr int THREADS = 256;
+  static constexpr size_t WORDS = 4096;   // 8-byte words per workgroup
+  struct Params { const CopyJob* jobs; u32 njobs; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int bx, int by, int tid, int nthreads, unsigned char*) {
+    if ((u32)by >= p.njobs) return;
+    const CopyJob j = p.jobs[by];
+    const size_t nw = j.bytes / 8, w0 = (size_t)bx * WORDS;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(j.src);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(j.dst);
+    for (size_t i = w0 + (size_t)tid; i < w0 + WORDS && i < nw; i += (size_t)nthreads) dst[i] = src[i];
+  }
+};
+// top of a sharded tree: the W all-gathered (root | aux) records -> W contiguous roots, and the maximum of the ranks' aux words (the trimmed length of a
+// distributed round polynomial rides on the root all-gather: no collective of its own)
+struct ShardTopKernel {
+  static constexpr int THREADS = 64;
+  static constexpr int REC = 64;   // bytes per rank: 32-byte root, 8-byte aux, padding
+  struct Params { const unsigned char* recs; u32 W; u32* top; unsigned long long* aux_max; };
+  static MS_HD int nphases(const Params&) { return 1; }
+  static MS_DEV void phase(int, const Params& p, int, int, int tid, int nthreads, unsigned char*) {
+    for (u32 i = (u32)tid; i < p.W * 8; i += (u32)nthreads) p.top[i] = reinterpret_cast<const u32*>(p.recs + (size_t)(i / 8) * REC)[i % 8];
+    if (tid == 0 && p.aux_max) {
+      unsigned long long m = 0;
+      for (u32 r = 0; r < p.W; r++) { const unsigned long long v = *reinterpret_cast<const unsigned long long*>(p.recs + (size_t)r * REC + 32); if (v > m) m = v; }
+      *p.aux_max = m;
+    }
+  }
+};
 // MerklePath of a sharded binary tree, same layout as PathKernel; every byte is written by exactly ONE rank
 // (the others leave zeros; the ranks' buffers are then summed):
 //   leaf index, leaf values, level count : the rank that evaluated the leaf group  (group % W)

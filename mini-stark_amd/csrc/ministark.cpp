@@ -127,7 +127,8 @@ template <class F> struct Ctx : CtxBase {
   void* rccl_comm = nullptr; DevBuf rccl_send, rccl_recv;   // ms_set_shard_rccl: the library owns the communicator and the exchange buffers
   u64 xstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // calls per op [0..3], bytes sent per op [4..7] (ms_shard_stats)
   int exchange(int op, size_t bytes) {
-    xstat[op & 3]++; xstat[4 + (op & 3)] += (op == MS_XCHG_ALL_TO_ALL ? bytes * (size_t)(sh_world - 1) : bytes);
+    { const int slot = (op == MS_XCHG_GATHER) ? 1 : (op & 3);   // (the gather to rank 0 is counted with the all-gathers)
+      xstat[slot]++; xstat[4 + slot] += (op == MS_XCHG_ALL_TO_ALL ? bytes * (size_t)(sh_world - 1) : (op == MS_XCHG_GATHER && sh_rank == 0 ? 0 : bytes)); }
     if (rccl_comm) {
       // RCCL on the context's stream: stream-ordered with the kernels on both sides, no host synchronisation, no host callback
       msrt::Rccl& R = msrt::Rccl::get();
@@ -141,6 +142,13 @@ template <class F> struct Ctx : CtxBase {
         }
         const int e2 = R.group_end();
         if (!e) e = e2;
+      } else if (op == MS_XCHG_GATHER) {   // to rank 0 only: chunk r of its receive buffer from rank r
+        e = R.group_start();
+        if (sh_rank != 0) { if (!e) e = R.send(xs, bytes, 1, 0, rccl_comm, stream); }
+        else for (int r = 1; r < W && !e; r++) e = R.recv(xr + (size_t)r * bytes, bytes, 1, r, rccl_comm, stream);
+        const int e2 = R.group_end();
+        if (!e) e = e2;
+        if (!e && sh_rank == 0 && msrt::d2d(xr, xs, bytes, stream)) e = -1;
       } else if (op == MS_XCHG_ALL_GATHER) e = R.all_gather(xs, xr, bytes, 1, rccl_comm, stream);
       else if (op == MS_XCHG_ALL_REDUCE_MIN_U64) e = R.all_reduce(xs, xs, bytes / 8, 5 /* ncclUint64 */, 3 /* ncclMin */, rccl_comm, stream);
       else e = R.all_reduce(xs, xs, bytes, 1, 0 /* ncclSum */, rccl_comm, stream);
@@ -802,14 +810,39 @@ template <class F> struct Ctx : CtxBase {
     }
     msmerkle::InterleaveDigestsKernel::Params ik{reinterpret_cast<const msmerkle::uint4_t*>(xr), reinterpret_cast<msmerkle::uint4_t*>(nodes.p), per, (u32)W};
     CK(run<msmerkle::InterleaveDigestsKernel>(K_IO, grid1(Mloc * 2, msmerkle::InterleaveDigestsKernel::THREADS), 1, msmerkle::InterleaveDigestsKernel::THREADS, 0, ik));
+    return finish_sharded_tree(ts, nodes, Mloc);
+  }
+  // the subtree over this rank's Mloc contiguous leaf digests (at nodes[0..)), the all-gather of the W subtree roots, the replicated top.
+  // shard_aux (a device word, optional): rides on the root all-gather; every rank gets the maximum over the ranks back in the same word.
+  unsigned long long* shard_aux = nullptr;
+  int finish_sharded_tree(TreeShape& ts, DevBuf& nodes, size_t Mloc) {
+    const size_t W = (size_t)sh_world, sub_nodes = 2 * Mloc - 1, top_nodes = 2 * W - 1;
+    constexpr size_t REC = msmerkle::ShardTopKernel::REC;
+    if (W * REC > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small for the subtree roots");
     RQ(inner_levels(nodes.as<u32>(), Mloc, 2, false));
+    CK(msrt::memset_dev(xs, 0, REC, stream));
     CK(msrt::d2d(xs, nodes.as<u8>() + (sub_nodes - 1) * 32, 32, stream));
-    RQ(exchange(MS_XCHG_ALL_GATHER, 32));
+    if (shard_aux) CK(msrt::d2d(xs + 32, shard_aux, 8, stream));
+    RQ(exchange(MS_XCHG_ALL_GATHER, REC));
     u8* top = nodes.as<u8>() + sub_nodes * 32;
-    CK(msrt::d2d(top, xr, W * 32, stream));
+    msmerkle::ShardTopKernel::Params tk{xr, (u32)W, reinterpret_cast<u32*>(top), shard_aux};
+    CK(run<msmerkle::ShardTopKernel>(K_IO, 1, 1, msmerkle::ShardTopKernel::THREADS, 0, tk));
+    shard_aux = nullptr;
     RQ(inner_levels(reinterpret_cast<u32*>(top), W, 2));
     ts.sharded = true; ts.Mloc = Mloc; ts.local_nodes = sub_nodes + top_nodes;
     return 0;
+  }
+  // MerkleTree::new over data EVERY rank holds (the raw trace): rank k hashes the contiguous leaf groups [k*M/W, (k+1)*M/W) - no digest exchange at all -
+  // builds that subtree, and the ranks all-gather the W subtree roots
+  template <int EL>
+  int tree_build_sharded_contiguous(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, TreeShape& ts, DevBuf& nodes) {
+    const size_t W = (size_t)sh_world, M = ts.leaf_num / ts.lpn, Mloc = M / W;
+    if (ts.ic != 2 || Mloc == 0 || (Mloc >> 32)) return fail(MS_ERR_STATE, "sharded tree needs a binary tree with at least world leaf groups");
+    if (nodes.ensure((2 * Mloc - 1 + 2 * W - 1) * 32)) return fail(MS_ERR_NOMEM, "merkle nodes");
+    // group g of the launch is leaf group rank*Mloc + g (one run of Mloc groups); its digest lands at nodes[g]: the kernel indexes `nodes` by the global group
+    u32* out = nodes.as<u32>() - (size_t)sh_rank * Mloc * 8;
+    RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, out, (size_t)sh_rank * Mloc, (u32)Mloc, 0)));
+    return finish_sharded_tree(ts, nodes, Mloc);
   }
   // root of the tree built LAST on this context (every caller reads it right behind the build)
   int read_root(const DevBuf& nodes, const TreeShape& ts, u8* root) {
@@ -830,7 +863,25 @@ template <class F> struct Ctx : CtxBase {
   TreeShape trace_ts, lde_ts;
   size_t lde_c = 0;
 
-  struct Round { DevBuf poly, cw, nodes; size_t cap = 0, ncoef = 0, D = 0; TreeShape ts; size_t m = 0; /* sharded: local codeword = limbs x 2 cosets x m */ };
+  // dist (one proof over several ranks, r04): the round polynomial is worked on BY COEFFICIENT RANGE - rank k owns the coefficients [k*S, (k+1)*S), S = D / (blowup * world).
+  // Round 0 keeps the whole (replicated) validity polynomial in `poly` and every rank uses its range of it; later rounds hold only their own S coefficients
+  // (local_store: limb l of coefficient k*S + i at poly[l*S + i]).
+  struct Round { DevBuf poly, cw, nodes; size_t cap = 0, ncoef = 0, D = 0; TreeShape ts; size_t m = 0; /* sharded: local codeword = limbs x 2 cosets x m */
+                 bool dist = false, local_store = false; size_t S = 0; };
+  int shard_dist = 1;          // MS_SHARD_DIST=0: the coefficient-domain work of a sharded proof stays replicated on every rank (r03 behaviour; A/B and tests)
+  int proof_root_only = 0;     // ms_shard_proof_on_root: the FRI proof blob is assembled on rank 0 only
+  const T* lpoly(const Round* r) const { return r->local_store ? r->poly.template as<T>() : r->poly.template as<T>() + (size_t)sh_rank * r->S; }
+  size_t lstride(const Round* r) const { return r->local_store ? r->S : r->cap; }
+  size_t lcount(const Round* r, size_t n) const { const size_t lo = (size_t)sh_rank * r->S; return n <= lo ? 0 : (n - lo < r->S ? n - lo : r->S); }
+  // chunk of a distributed round polynomial on a domain of D points (0: the round stays replicated): the commitment must be sharded and the chunk even
+  size_t dist_chunk(size_t D) const {
+    if (sh_world <= 1 || !shard_dist || !fri_blowup || !shardable(D / 2)) return 0;
+    const size_t den = fri_blowup * (size_t)sh_world;
+    if (D % den) return 0;
+    const size_t S = D / den;
+    return (S >= 2 && !(S & 1)) ? S : 0;
+  }
+  DevBuf d_carry, d_lq, d_pack, d_fullpoly;
   std::vector<Round*> rounds; size_t nrounds_done = 0, fri_rounds = 0, fri_blowup = 0;
   bool have_deep = false; XE cur_z; XE cur_B[2];
   DevBuf d_folded, d_sh, d_blob, d_tabs, d_targets, d_idx, d_deg, d_ovf;
@@ -868,12 +919,14 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_LDE_MULTI")) lde_multi = atoi(e);
     if (const char* e = getenv("MS_LDE_VIRTUAL")) lde_virtual = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
+    if (const char* e = getenv("MS_UPLOAD")) upload_sdma = !strcmp(e, "sdma") ? 1 : 0;
     if (const char* e = getenv("MS_READBACK")) readback_sdma = !strcmp(e, "hip") ? 0 : (!strcmp(e, "sdma-all") ? 2 : 1);
     if (const char* e = getenv("MS_LEAF_LAZY_MIN")) leaf_lazy_min = atoi(e);
     if (const char* e = getenv("MS_TREE_TOP")) { int v = atoi(e); if (v >= 1 && v <= 65536) tree_top_parents = v; }
     if (const char* e = getenv("MS_NTT_FAST_MIN")) ntt_fast_min = atoi(e);
     if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
     if (const char* e = getenv("MS_SHARD_MIN_LEAVES")) { long v = atol(e); if (v >= 1) shard_min_leaves = (size_t)v; }
+    if (const char* e = getenv("MS_SHARD_DIST")) shard_dist = atoi(e);
     if (const char* e = getenv("MS_SHARD_SLICES")) { int v = atoi(e); if (v >= 1 && v <= 64) shard_slices = v; }
     if (const char* e = getenv("MS_SHARD_SLICE_MIN")) { long v = atol(e); if (v >= 1) shard_slice_min = (size_t)v; }
     CK(msrt::set_device(dev));
@@ -889,7 +942,7 @@ template <class F> struct Ctx : CtxBase {
     drop_rccl();
     if (sdma_pending) msrt::Sdma::get().wait(sdma_sig, 20.0);
     else if (copy_pending) msrt::event_sync(ev_copy);
-    if (sdma_state == 1) msrt::Sdma::get().signal_destroy(sdma_sig);
+    if (sdma_state == 1) { msrt::Sdma::get().signal_destroy(sdma_sig); msrt::Sdma::get().signal_destroy(sdma_up_sig); }
     for (msrt::Event* e : ev_hash) msrt::event_destroy(e);
     for (msrt::Event* e : ev_xchg) msrt::event_destroy(e);
     if (comm_stream) msrt::stream_destroy(comm_stream);
@@ -897,7 +950,7 @@ template <class F> struct Ctx : CtxBase {
     if (ev_copy) msrt::event_destroy(ev_copy);
     if (copy_stream) msrt::stream_destroy(copy_stream);
     for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
-    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero, &d_lin, &d_cubic};
+    DevBuf* bufs[] = {&ntt_scratch, &d_trace, &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero, &d_lin, &d_cubic, &d_carry, &d_lq, &d_pack, &d_fullpoly};
     for (DevBuf* b : bufs) b->release();
     if (pinned) msrt::free_host(pinned);
     if (h_tabs) msrt::free_host(h_tabs);
@@ -936,7 +989,8 @@ template <class F> struct Ctx : CtxBase {
     if (ctz64(N_) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "trace domain larger than the field's two-adicity (air.rs:74)");
     TreeShape ts;
     RQ(tree_shape(N_ * w_, lpn, 2, &ts));
-    if (!on_device && !canonical(trace, N_ * w_)) return fail(MS_ERR_ARG, "trace element not canonical (>= p)");
+    // (the canonical range of the trace is checked by the transposing kernel for host and device input alike: a host-side scan of the N x w matrix
+    //  cost ~3 ms of the proving thread per 2^20-row proof, with its stream idle - r04, I/O leg)
     have_trace = have_polys = have_lde = have_validity = false; npolys = 0; nrounds_done = 0; have_deep = false; blob_size = 0;
     if (N_ != N) { polys_cap = 0; d_polys.release(); }
     N = N_; w = w_;
@@ -944,7 +998,16 @@ template <class F> struct Ctx : CtxBase {
     if (on_device) dsrc = trace;
     else {
       if (d_trace.ensure(N * w * 8)) return fail(MS_ERR_NOMEM, "trace");
-      CK(msrt::h2d(d_trace.p, trace, N * w * 8, stream));
+      bool sent = false;
+      if (upload_sdma && sdma_ready() && msrt::is_pinned_host(trace)) {   // MS_UPLOAD=sdma: the trace on an SDMA engine through the HSA runtime (page-locked sources only); the host waits for it
+        msrt::Sdma& S = msrt::Sdma::get();
+        CK(msrt::sync(stream));                                           // d_trace may still be read by the previous proof's transposing kernel
+        if (S.h2d_engine(sdma_gpu) && !S.copy_h2d(sdma_gpu, d_trace.p, trace, N * w * 8, sdma_up_sig, S.h2d_engine(sdma_gpu))) {
+          if (S.wait(sdma_up_sig, 20.0)) return fail(MS_ERR_HIP, "SDMA upload did not complete within 20 s");
+          sent = true;
+        }
+      }
+      if (!sent) CK(msrt::h2d(d_trace.p, trace, N * w * 8, stream));
       dsrc = d_trace.as<u64>();
     }
     RQ(ensure_polys(w + 1));
@@ -1271,7 +1334,7 @@ template <class F> struct Ctx : CtxBase {
   int degree_launch1(const T* poly, size_t n, unsigned long long** dres_out) {   // trimmed length of a base-field coefficient vector
     void* zr;
     RQ(zero_alloc(8, &zr));
-    typename mspoly::DegreeKernel<F, 1>::Params dp{poly, 0, n, reinterpret_cast<unsigned long long*>(zr)};
+    typename mspoly::DegreeKernel<F, 1>::Params dp{poly, 0, n, reinterpret_cast<unsigned long long*>(zr), 0};
     CK(run<mspoly::DegreeKernel<F, 1>>(K_DEGREE, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
     *dres_out = reinterpret_cast<unsigned long long*>(zr);
     return 0;
@@ -1313,10 +1376,47 @@ template <class F> struct Ctx : CtxBase {
   }
   static bool load_ext(const u64* v, XE* out) { for (int l = 0; l < E; l++) { if (v[l] >= F::P) return false; out->c[l] = F::from_u64(v[l]); } return true; }
 
+  // sharded proof: out[i] = sum_r part_r[i] * zstep^r for n extension elements of the all-gathered partials (rank r's payload rank_stride limbs apart, the elements from `off` on)
+  int shard_combine_launch(size_t off, size_t rank_stride, u32 n, const XE& zstep, T* out) {
+    typedef mspoly::ShardCombineKernel<F, E> CKn;
+    typename CKn::Params cp{reinterpret_cast<const T*>(xr) + off, rank_stride, n, (u32)sh_world, zstep, out};
+    CK(run<CKn>(K_EVAL_REDUCE, grid1(n, CKn::THREADS), 1, CKn::THREADS, 0, cp));
+    return 0;
+  }
+  // DEEP-ALI evaluations by coefficient range (r04): rank k evaluates the coefficients [k*Sx, (k+1)*Sx) of every polynomial at every point, ONE all-gather of the partial
+  // sums, and every rank combines them with z^Sx
+  bool dist_eval() const { return sh_world > 1 && shard_dist && N >= shard_min_leaves && N >= (size_t)sh_world * 2; }
+  int eval_ext_sharded(const u64* z, int q, u64* out) {
+    const int np = npolys + 1;
+    const size_t tot = (size_t)q * np * E, W = (size_t)sh_world;
+    const size_t maxlen = validity_len > N ? validity_len : N, Sx = maxlen / W, lo = (size_t)sh_rank * Sx;
+    if (tot * sizeof(T) > pinned_cap) return fail(MS_ERR_ARG, "too many evaluation points");
+    if (tot * sizeof(T) * W > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small for the DEEP-ALI partial sums");
+    std::vector<XE> zs((size_t)q);
+    for (int t = 0; t < q; t++) {
+      if (!load_ext(z + (size_t)t * E, &zs[t])) return fail(MS_ERR_ARG, "query point not canonical");
+      for (int i0 = 0; i0 < np; i0 += mspoly::MAX_POLYS) {
+        const int nb = (np - i0 < mspoly::MAX_POLYS) ? np - i0 : mspoly::MAX_POLYS;
+        size_t off[mspoly::MAX_POLYS], cnt[mspoly::MAX_POLYS];
+        for (int i = 0; i < nb; i++) { const size_t len = (i0 + i == npolys) ? validity_len : N; off[i] = lo; cnt[i] = len <= lo ? 0 : (len - lo < Sx ? len - lo : Sx); }
+        RQ((eval_views<1>(d_polys.as<T>() + (size_t)i0 * N, N, 0, 1, off, cnt, nb, zs[t], reinterpret_cast<T*>(xs) + ((size_t)t * np + i0) * E)));
+      }
+    }
+    if (tot) {
+      RQ(exchange(MS_XCHG_ALL_GATHER, tot * sizeof(T)));
+      for (int t = 0; t < q; t++) RQ(shard_combine_launch((size_t)t * np * E, tot, (u32)np, e_pow<F, E>(zs[t], (u64)Sx), reinterpret_cast<T*>(pinned) + (size_t)t * np * E));
+      CK(msrt::sync(stream));
+      const T* h = reinterpret_cast<const T*>(pinned);
+      for (size_t i = 0; i < tot; i++) out[i] = F::to_u64(h[i]);
+    }
+    return MS_OK;
+  }
+
   // ------------------------------------------------------------------ starks.rs:124-151
   int eval_ext(const u64* z, int q, u64* out) override {
     if (!have_validity) return fail(MS_ERR_STATE, "eval_ext before mix");
     if (!z || !out || q < 0) return fail(MS_ERR_ARG, "eval_ext");
+    if (dist_eval()) return eval_ext_sharded(z, q, out);
     const int np = npolys + 1;
     const size_t tot = (size_t)q * np * E;
     if (d_small.ensure(tot * sizeof(T) + 4096)) return fail(MS_ERR_NOMEM, "small");
@@ -1385,7 +1485,14 @@ template <class F> struct Ctx : CtxBase {
       const size_t m = r->D / (2 * (size_t)sh_world);
       r->m = m;
       if (r->cw.ensure(2 * m * E * sizeof(T))) return fail(MS_ERR_NOMEM, "codeword");
-      RQ(coset_eval(r->poly.template as<T>(), r->cap, ncoef_in, ctz64(r->D), F::from_u64(1), 2, r->cw.template as<T>(), 2 * m, (size_t)nonzero_limbs));
+      const T* coef = r->poly.template as<T>(); size_t coef_stride = r->cap;
+      if (r->local_store) {   // the transform needs every coefficient (a DEEP point in the base field / MS_FRI_POINTWISE=0): gather the parts of the distributed polynomial
+        const size_t full = r->S * (size_t)sh_world;
+        if (d_fullpoly.ensure(full * E * sizeof(T))) return fail(MS_ERR_NOMEM, "gathered polynomial");
+        if (ncoef_in) RQ(gather_poly(lpoly(r), r->S, ncoef_in, d_fullpoly.as<T>(), full));
+        coef = d_fullpoly.as<T>(); coef_stride = full;
+      }
+      RQ(coset_eval(coef, coef_stride, ncoef_in, ctz64(r->D), F::from_u64(1), 2, r->cw.template as<T>(), 2 * m, (size_t)nonzero_limbs));
       if (nonzero_limbs < E) CK(msrt::memset_dev(r->cw.template as<T>() + (size_t)nonzero_limbs * 2 * m, 0, (size_t)(E - nonzero_limbs) * 2 * m * sizeof(T), stream));
       RQ((tree_build_sharded<E>(r->cw.template as<T>(), m, 1, 2 * m, 2, r->ts, r->nodes)));
       return 0;
@@ -1402,7 +1509,7 @@ template <class F> struct Ctx : CtxBase {
     RQ(zero_alloc(8, &zr));
     unsigned long long* dres = reinterpret_cast<unsigned long long*>(zr);
     if (n) {
-      typename mspoly::DegreeKernel<F, E>::Params dp{poly, limb_stride, n, dres};
+      typename mspoly::DegreeKernel<F, E>::Params dp{poly, limb_stride, n, dres, 0};
       CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(n, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
     }
     *dres_out = dres;
@@ -1440,6 +1547,7 @@ template <class F> struct Ctx : CtxBase {
     size_t dsize = (deg + 1) * blowup_;  // fri.rs:74 (quirk Q11)
     size_t D = 1; while (D < dsize) D <<= 1;
     r->D = D;
+    r->S = dist_chunk(D); r->dist = r->S != 0; r->local_store = false;   // the validity polynomial is replicated: a distributed round 0 means every rank WORKS on its range of it
     RQ(round_commit(r, nc, 1));
     RQ(read_root(r->nodes, r->ts, root0));
     nrounds_done = 1;
@@ -1453,6 +1561,13 @@ template <class F> struct Ctx : CtxBase {
     Round* r = rounds[nrounds_done - 1];
     size_t off[2] = {0, 1}, cnt[2] = {(r->ncoef + 1) / 2, r->ncoef / 2};
     T* dst = reinterpret_cast<T*>(pinned);   // the last kernel of the evaluation stores its 2 E words straight into page-locked host memory
+    if (r->dist) {   // even(z), odd(z) by coefficient range: partial sums over this rank's coefficients, one all-gather, combination with z^(S/2)
+      const size_t lc = lcount(r, r->ncoef);
+      cnt[0] = (lc + 1) / 2; cnt[1] = lc / 2;   // (the rank's first coefficient has an even index: S is even)
+      RQ((eval_views<E>(lpoly(r), 0, lstride(r), 2, off, cnt, 2, cur_z, reinterpret_cast<T*>(xs))));
+      RQ(exchange(MS_XCHG_ALL_GATHER, 2 * E * sizeof(T)));
+      RQ(shard_combine_launch(0, 2 * E, 2, e_pow<F, E>(cur_z, (u64)(r->S / 2)), dst));
+    } else
     RQ((eval_views<E>(r->poly.template as<T>(), 0, r->cap, 2, off, cnt, 2, cur_z, dst)));  // fri.rs:354-359
     CK(msrt::sync(stream));
     const T* h = reinterpret_cast<const T*>(pinned);
@@ -1466,7 +1581,8 @@ template <class F> struct Ctx : CtxBase {
   // (aggregates = input of the level above, carries = output of the level above) come from d_sh.
   typedef mspoly::SHJob<F, E> SHJ;
   typedef mspoly::SuffixHornerKernel<F, E> SHK;
-  struct SHPlan { int nl; std::vector<SHJ> agg; std::vector<SHJ> fin; };  // agg[l] for l < nl-1, fin[l] for l < nl
+  struct SHPlan { int nl; std::vector<SHJ> agg; std::vector<SHJ> fin; bool has_top_agg = false; SHJ top_agg; size_t P = 0; };  // agg[l] for l < nl-1, fin[l] for l < nl
+  // (P = BS^nl: where the kernel places a carry-in of the top level, in elements of the job)
   static size_t sh_scratch_elems(size_t m) {
     const size_t BS = mspoly::SH_BS;
     size_t tot = 0, cur = m;
@@ -1474,8 +1590,11 @@ template <class F> struct Ctx : CtxBase {
     return tot;
   }
   // `scratch` must hold sh_scratch_elems(m) elements of T
+  // ext_carry (E limbs, device): carry-in of the top level (a rank of a sharded proof: the suffix sum over the higher ranks, scaled - ShardCarryKernel);
+  // top_agg (E limbs, device): the job's aggregate over all its elements, stored by one extra AGG launch of the top level; out_h0: see SHJob
   SHPlan sh_plan(const T* in, size_t in_limb_stride, size_t in_off, size_t in_stride, size_t m, const XE& z,
-                 void* out, bool out_u64, size_t out_limb_stride, size_t out_off, size_t out_stride, T* h0, T* scratch) {
+                 void* out, bool out_u64, size_t out_limb_stride, size_t out_off, size_t out_stride, T* h0, T* scratch,
+                 const T* ext_carry = nullptr, T* top_agg = nullptr, bool out_h0 = false) {
     const size_t BS = mspoly::SH_BS;
     std::vector<size_t> ms; ms.push_back(m);
     while ((ms.back() ? (ms.back() + BS - 1) / BS : 1) > 1) ms.push_back((ms.back() + BS - 1) / BS);
@@ -1499,13 +1618,19 @@ template <class F> struct Ctx : CtxBase {
         SHJ a = j; a.agg = scratch + aoff[l]; a.agg_limb_stride = nbs[l];
         pl.agg[l] = a;
         j.carry = scratch + coff[l]; j.carry_limb_stride = nbs[l];
+      } else {
+        if (top_agg) { SHJ a = j; a.agg = top_agg; a.agg_limb_stride = 1; pl.top_agg = a; pl.has_top_agg = true; }
+        if (ext_carry) { j.carry = ext_carry; j.carry_limb_stride = 1; }
       }
-      if (l == 0) { j.out = out; j.out_u64 = out_u64 ? 1 : 0; j.out_limb_stride = out_limb_stride; j.out_off = out_off; j.out_stride = out_stride; j.h0 = h0; }
+      if (l == 0) { j.out = out; j.out_u64 = out_u64 ? 1 : 0; j.out_limb_stride = out_limb_stride; j.out_off = out_off; j.out_stride = out_stride; j.h0 = h0; j.out_h0 = out_h0 ? 1 : 0; }
       else { j.out = scratch + coff[l - 1]; j.out_u64 = 0; j.out_limb_stride = nbs[l - 1]; j.out_off = 0; j.out_stride = 1; j.tail_zero = 1; }
       pl.fin[l] = j;
     }
+    pl.P = 1; for (int l = 0; l < nl; l++) pl.P *= BS;
     return pl;
   }
+  // z^(m - P) = (1/z)^(P - m): moves a top-level carry-in from the padded position P to the job's end m (0 for z = 0: nothing then carries over)
+  static XE carry_scale(const XE& z, size_t m, size_t P) { return e_pow<F, E>(e_inv<F>(z), (u64)(P - m)); }
   int sh_launch_inline(const SHJ& j, int final_mode) {
     typename SHK::Params p; p.jobs = nullptr; p.inline_job = j; p.final_mode = final_mode;
     const size_t nb = j.m ? (j.m + mspoly::SH_BS - 1) / mspoly::SH_BS : 1;
@@ -1522,6 +1647,73 @@ template <class F> struct Ctx : CtxBase {
     return 0;
   }
 
+  // all-gather of a distributed round polynomial's parts into one replicated vector (dst: E limbs, dst_stride apart, `count` coefficients)
+  int gather_poly(const T* local, size_t S, size_t count, T* dst, size_t dst_stride) {
+    const size_t bytes = S * E * sizeof(T);
+    if (bytes * (size_t)sh_world > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small to gather a round polynomial");
+    CK(msrt::d2d(xs, local, bytes, stream));
+    RQ(exchange(MS_XCHG_ALL_GATHER, bytes));
+    typedef mspoly::GatherPolyKernel<F, E> GK;
+    typename GK::Params gp{reinterpret_cast<const T*>(xr), S * E, S, count, dst, dst_stride};
+    CK(run<GK>(K_IO, grid1(count * E, GK::THREADS), 1, GK::THREADS, 0, gp));
+    return 0;
+  }
+  // fri.rs:96-101 on a DISTRIBUTED round polynomial (r04): rank k folds its own coefficient pairs, runs the suffix Horner of (folded - B(alpha)) / (x - z) over its
+  // own range with the sum over the higher ranks as carry-in (one all-gather of [first folded element | aggregate] per rank, ShardCarryKernel), and ends up with
+  // its range [k*S', (k+1)*S') of the quotient = the next round polynomial, S' = S/2.  If the next round is too small to stay distributed the parts are
+  // all-gathered into a replicated polynomial.  H_j for j in (lo, hi) comes from the rank's own job over f[lo+1 .. hi); H_hi = q_(hi-1) IS the carry-in.
+  int fold_dist(Round* pr, Round* nr, const XE& a, size_t* nq_coef_out) {
+    const size_t n = pr->ncoef, m = (n + 1) / 2, Sn = pr->S / 2;
+    const bool next_dist = dist_chunk(nr->D) == Sn;
+    const size_t cntp = lcount(pr, n), cnt = (cntp + 1) / 2;   // this rank's coefficients of the round polynomial / of the folded polynomial
+    T* lq;
+    if (next_dist) { if (nr->poly.ensure(Sn * E * sizeof(T))) return fail(MS_ERR_NOMEM, "fold"); lq = nr->poly.template as<T>(); }
+    else { if (d_lq.ensure(Sn * E * sizeof(T))) return fail(MS_ERR_NOMEM, "fold"); lq = d_lq.as<T>(); }
+    if (d_folded.ensure((Sn + 1) * E * sizeof(T)) || d_carry.ensure(4096)) return fail(MS_ERR_NOMEM, "fold");
+    if (4 * E * sizeof(T) * (size_t)sh_world > xcap) return fail(MS_ERR_NOMEM, "exchange buffers");
+    size_t nq_coef = 0;
+    if (m >= 2) {
+      typename mspoly::FoldKernel<F, E>::Params fp{lpoly(pr), lstride(pr), cntp, d_folded.as<T>(), Sn, a};  // fri.rs:361-372
+      CK(run<mspoly::FoldKernel<F, E>>(K_FOLD, grid1(cnt, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
+      T* pay = reinterpret_cast<T*>(xs);        // [first folded element (E limbs) | aggregate of the job (E limbs)]
+      CK(msrt::memset_dev(xs, 0, 2 * E * sizeof(T), stream));
+      if (cnt) {
+        typename mspoly::CopyLimbsKernel<F>::Params cl{d_folded.as<T>(), Sn, pay, 1, (u32)E};
+        CK(run<mspoly::CopyLimbsKernel<F>>(K_IO, 1, 1, mspoly::CopyLimbsKernel<F>::THREADS, 0, cl));
+      }
+      const size_t mj = cnt ? cnt - 1 : 0;
+      SHPlan pl; pl.nl = 0;
+      if (mj) {
+        if (d_sh.ensure(sh_scratch_elems(mj) * sizeof(T))) return fail(MS_ERR_NOMEM, "scan levels");
+        pl = sh_plan(d_folded.as<T>(), Sn, 1, 1, mj, cur_z, lq, false, Sn, 1, 1, nullptr, d_sh.as<T>(), d_carry.as<T>(), pay + E, true);
+        for (int l = 0; l + 1 < pl.nl; l++) RQ(sh_launch_inline(pl.agg[l], 0));
+        RQ(sh_launch_inline(pl.top_agg, 0));
+      }
+      RQ(exchange(MS_XCHG_ALL_GATHER, 2 * E * sizeof(T)));
+      typedef mspoly::ShardCarryKernel<F, E> CKn;
+      typename CKn::Params cp;
+      memset(&cp, 0, sizeof cp);
+      cp.jobs = nullptr; cp.njobs = 1; cp.W = (u32)sh_world; cp.rank = (u32)sh_rank; cp.gathered = reinterpret_cast<const T*>(xr); cp.rank_stride = 2 * E;
+      cp.inline_job.first_off = 0; cp.inline_job.agg_off = E; cp.inline_job.has_first = 1;
+      cp.inline_job.zA = cur_z; cp.inline_job.zB = e_pow<F, E>(cur_z, (u64)(Sn - 1));
+      cp.inline_job.scale = mj ? carry_scale(cur_z, mj, pl.P) : e_one<F, E>();
+      cp.inline_job.carry_out = d_carry.as<T>();
+      cp.inline_job.tail_out = cnt ? lq + (cnt - 1) : nullptr; cp.inline_job.tail_stride = Sn;   // q_(hi-1) = H_hi (zero, and beyond the polynomial, on the rank that holds its top)
+      cp.inline_job.h0_out = nullptr;
+      CK(run<CKn>(K_SUFFIX_HORNER, 1, 1, CKn::THREADS, 0, cp));
+      if (mj) for (int l = pl.nl - 1; l >= 0; l--) RQ(sh_launch_inline(pl.fin[l], 1));
+      nq_coef = m - 1;
+    }
+    nr->S = Sn;
+    if (next_dist) { nr->dist = true; nr->local_store = true; }
+    else {   // the round after this one is small: replicate the quotient (one all-gather of S' coefficients per rank) and go on as an unsharded prover would
+      if (nr->poly.ensure(nr->cap * E * sizeof(T))) return fail(MS_ERR_NOMEM, "fold");
+      if (nq_coef) RQ(gather_poly(lq, Sn, nq_coef, nr->poly.template as<T>(), nr->cap));
+      nr->S = 0;
+    }
+    *nq_coef_out = nq_coef;
+    return 0;
+  }
   // fri.rs:96-109
   int fri_fold_commit(const u64* alpha, u8* root) override {
     if (!have_deep) return fail(MS_ERR_STATE, "fri_fold_commit before fri_deep");
@@ -1533,8 +1725,11 @@ template <class F> struct Ctx : CtxBase {
     Round* nr = round_slot(nrounds_done);
     nr->cap = m ? m : 1;
     nr->D = pr->D / 2;  // fri.rs:104, 374-376
-    if (nr->poly.ensure(nr->cap * E * sizeof(T)) || d_folded.ensure((m + 1) * E * sizeof(T))) return fail(MS_ERR_NOMEM, "fold");
+    nr->dist = false; nr->local_store = false; nr->S = 0;
     size_t nq_coef = 0;
+    if (pr->dist) RQ(fold_dist(pr, nr, a, &nq_coef));
+    else {
+    if (nr->poly.ensure(nr->cap * E * sizeof(T)) || d_folded.ensure((m + 1) * E * sizeof(T))) return fail(MS_ERR_NOMEM, "fold");
     if (m >= 2) {
       typename mspoly::FoldKernel<F, E>::Params fp{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a};  // fri.rs:361-372
       CK(run<mspoly::FoldKernel<F, E>>(K_FOLD, grid1(m, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
@@ -1542,18 +1737,26 @@ template <class F> struct Ctx : CtxBase {
       RQ(suffix_horner(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), nr->cap, 0, 1, nullptr));
       nq_coef = m - 1;
     }
+    }
     // the degree scan runs BEFORE the commitment and the tree's final launch forwards its 8-byte result, with the root, into page-locked host memory:
     // no copy launch in front of the round's one stream synchronisation (r03; the trace showed a 4 us copyBuffer kernel + its launch gap per round)
     // (the word lives in d_deg, zeroed once: the forwarding thread clears it again - the pool of zero_alloc may be wiped while the tree is being built)
     if (!d_deg.p) { if (d_deg.ensure(256)) return fail(MS_ERR_NOMEM, "degree word"); CK(msrt::memset_dev(d_deg.p, 0, 256, stream)); }
     unsigned long long* dres = d_deg.as<unsigned long long>();
-    if (nq_coef) {
-      typename mspoly::DegreeKernel<F, E>::Params dp{nr->poly.template as<T>(), nr->cap, nq_coef, dres};
+    if (nr->dist) {   // this rank's part reports the GLOBAL trimmed length; the maximum over the ranks comes back with the subtree roots (finish_sharded_tree)
+      const size_t lc = lcount(nr, nq_coef);
+      if (lc) {
+        typename mspoly::DegreeKernel<F, E>::Params dp{lpoly(nr), lstride(nr), lc, dres, (size_t)sh_rank * nr->S};
+        CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(lc, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
+      }
+      shard_aux = dres;
+    } else if (nq_coef) {
+      typename mspoly::DegreeKernel<F, E>::Params dp{nr->poly.template as<T>(), nr->cap, nq_coef, dres, 0};
       CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(nq_coef, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
     }
     pending_aux = dres; aux_on_host = false;
     RQ(round_commit(nr, nq_coef, E, pr, &a));
-    pending_aux = nullptr;
+    pending_aux = nullptr; shard_aux = nullptr;
     if (!aux_on_host) { CK(msrt::d2h(pinned, dres, 8, stream)); CK(msrt::memset_dev(dres, 0, 8, stream)); }
     if (!root_on_host) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, nr->nodes.template as<u8>() + (nr->ts.local_nodes - 1) * 32, 32, stream));
     CK(msrt::sync(stream));
@@ -1570,6 +1773,7 @@ template <class F> struct Ctx : CtxBase {
   }
   int fri_round_poly_read(int r, u64* out) override {
     if (r < 0 || (size_t)r >= nrounds_done || !out) return fail(MS_ERR_ARG, "round index");
+    if (rounds[r]->local_store) return fail(MS_ERR_STATE, "round_poly_read: the polynomial of a sharded round is distributed over the ranks");
     return download_widen(rounds[r]->poly.template as<T>(), rounds[r]->ncoef, rounds[r]->cap, E, out);
   }
   int fri_round_codeword_read(int r, u64* out) override {
@@ -1783,13 +1987,13 @@ template <class F> struct Ctx : CtxBase {
   // blit kernel; completion is an HSA signal the host waits on (ms_fri_proof_wait, or the next ms_fri_query before it rewrites the blob).  MS_READBACK=hip keeps
   // hipMemcpyAsync on the copy stream (A/B); io_engine() reports which path the last read-back took.
   int readback_sdma = 1, sdma_gpu = -1, sdma_state = 0 /* 0 untried, 1 bound, 2 unavailable */, last_io_engine = 0;
-  msrt::Sdma::Signal sdma_sig{0}; bool sdma_pending = false;
+  msrt::Sdma::Signal sdma_sig{0}, sdma_up_sig{0}; bool sdma_pending = false; int upload_sdma = 0;
   bool sdma_ready() {
     if (!readback_sdma) return false;
     if (sdma_state == 0) {
       sdma_state = 2;
       msrt::Sdma& S = msrt::Sdma::get();
-      if (!S.bind_device(device, &sdma_gpu) && !S.signal_create(&sdma_sig)) sdma_state = 1;
+      if (!S.bind_device(device, &sdma_gpu) && !S.signal_create(&sdma_sig) && !S.signal_create(&sdma_up_sig)) sdma_state = 1;
     }
     return sdma_state == 1;
   }

@@ -78,6 +78,8 @@ struct Sdma {
   int signal_create(Signal*) { return 1; }
   void signal_destroy(Signal) {}
   int copy_d2h(int, void*, const void*, size_t, Signal, unsigned) { return 1; }
+  int copy_h2d(int, void*, const void*, size_t, Signal, unsigned) { return 1; }
+  unsigned h2d_engine(int) { return 0; }
   int wait(Signal, double) { return 1; }
   unsigned d2h_engine(int) { return 0; }
 };
@@ -252,7 +254,7 @@ struct Sdma {
   decltype(&hsa_amd_memory_copy_engine_status) f_status = nullptr;
   decltype(&hsa_amd_memory_get_preferred_copy_engine) f_pref = nullptr;
   hsa_agent_t cpu{0}; bool have_cpu = false;
-  struct Gpu { hsa_agent_t agent; uint32_t bdf, domain; unsigned d2h_engine; };
+  struct Gpu { hsa_agent_t agent; uint32_t bdf, domain; unsigned d2h_engine, h2d_engine; };
   std::vector<Gpu> gpus;
   std::vector<int> dev_gpu;   // HIP device ordinal -> index into gpus (-1: not matched)
   static Sdma& get() { static Sdma s; return s; }
@@ -262,7 +264,7 @@ struct Sdma {
     if (S->f_agent_info(a, HSA_AGENT_INFO_DEVICE, &ty) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
     if (ty == HSA_DEVICE_TYPE_CPU) { if (!S->have_cpu) { S->cpu = a; S->have_cpu = true; } }
     else if (ty == HSA_DEVICE_TYPE_GPU) {
-      Gpu g; g.agent = a; g.bdf = 0; g.domain = 0; g.d2h_engine = 0;
+      Gpu g; g.agent = a; g.bdf = 0; g.domain = 0; g.d2h_engine = 0; g.h2d_engine = 0;
       S->f_agent_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &g.bdf);
       S->f_agent_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &g.domain);
       S->gpus.push_back(g);
@@ -314,6 +316,14 @@ struct Sdma {
           uint32_t m = (pref & avail) ? (pref & avail) : (avail ? avail : pref);
           g.d2h_engine = m ? (m & (~m + 1)) : 0;                           // lowest set bit
         }
+        if (const char* e = getenv("MS_SDMA_ENGINE_H2D")) g.h2d_engine = (unsigned)strtoul(e, nullptr, 0);
+        else {
+          avail = pref = 0;
+          f_status(g.agent, cpu, &avail);
+          if (f_pref) f_pref(g.agent, cpu, &pref);
+          uint32_t m = (pref & avail) ? (pref & avail) : (avail ? avail : pref);
+          g.h2d_engine = m ? (m & (~m + 1)) : 0;
+        }
         if (!g.d2h_engine) dev_gpu[hip_device] = -1;
       }
     }
@@ -322,6 +332,12 @@ struct Sdma {
     return 0;
   }
   unsigned d2h_engine(int gpu_index) { return gpus[gpu_index].d2h_engine; }
+  unsigned h2d_engine(int gpu_index) { return gpus[gpu_index].h2d_engine; }
+  // page-locked host memory -> device memory of `gpu_index`
+  int copy_h2d(int gpu_index, void* dst_dev, const void* src_host, size_t n, Signal sig, unsigned engine) {
+    f_sig_store(sig, 1);
+    return (int)f_copy(dst_dev, gpus[gpu_index].agent, src_host, cpu, n, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)engine, true);
+  }
   int signal_create(Signal* s) { return f_sig_create(1, 0, nullptr, s) == HSA_STATUS_SUCCESS ? 0 : 1; }
   void signal_destroy(Signal s) { if (s.handle) f_sig_destroy(s); }
   // device memory of `gpu_index` -> page-locked host memory, on SDMA engine `engine`; `sig` reads 0 when the bytes have landed

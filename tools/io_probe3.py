@@ -23,19 +23,23 @@ class G:
     def max_over_ranks(self, s): return s
 
 
-VARIANTS = [("resident", False, None, "sdma"), ("async_hip", True, "async", "hip"), ("async_sdma", True, "async", "sdma"),
-            ("blocking_hip", True, True, "hip"), ("blocking_sdma", True, True, "sdma-all")]
+# name, read-back on, read-back mode, MS_READBACK, upload on, MS_UPLOAD
+VARIANTS = [("resident", False, None, "sdma", False, "hip"), ("async_hip", True, "async", "hip", True, "hip"), ("async_sdma", True, "async", "sdma", True, "hip"),
+            ("blocking_hip", True, True, "hip", True, "hip"), ("blocking_sdma", True, True, "sdma-all", True, "hip"),
+            ("upload_only_hip", False, None, "sdma", True, "hip"), ("upload_only_sdma", False, None, "sdma", True, "sdma"),
+            ("readback_only_sdma", True, "async", "sdma", False, "hip"), ("async_sdma_upload_sdma", True, "async", "sdma", True, "sdma")]
 if args.only:
     VARIANTS = [v for v in VARIANTS if v[0] in args.only.split(",")]
 dev = torch.device("cuda", 0)
 lanes = {}
-for name, io, mode, rb in VARIANTS:
+for name, io, mode, rb, up, upm in VARIANTS:
     os.environ["MS_READBACK"] = rb
-    lanes[name] = bench.Lanes(0, 20, 8, args.inflight, 0, dev, io=io, io_mode=mode)
+    os.environ["MS_UPLOAD"] = upm
+    lanes[name] = bench.Lanes(0, 20, 8, args.inflight, 0, dev, io=io, io_mode=mode, upload=up)
 allres = {n: [] for n, *_ in VARIANTS}
 for r in range(args.rounds):
     res = {"pass": r}
-    for name, io, mode, rb in VARIANTS:
+    for name, io, mode, rb, up, upm in VARIANTS:
         ln = lanes[name]
         el = ln.timed(G(), args.steps, args.warmup)
         v = round(args.steps * args.inflight / el, 1)
