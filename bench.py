@@ -248,7 +248,15 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
     el = grp.max_over_ranks(time.perf_counter() - t0)
     mine = hs.last_proof(read_fri_proof=False)
     roots = grp.all_gather_bytes(mine.fri_roots[-1])
-    calls = xchg.calls
+    calls = dict(xchg.calls)     # (a snapshot: the profiled proof below goes through the same exchange)
+    nbytes = xchg.bytes
+    dist_rounds = sum(1 for i in range(cfg.rounds) if ctx.L.ms_shard_round_is_distributed(ctx.h, C.c_int(i)) == 1)
+    # one more (untimed) proof with every launch bracketed by HIP events: kernel time of this rank's PART of the proof vs kernel time REPLICATED on every rank
+    buf = C.create_string_buffer(1 << 14)
+    ctx.check(ctx.L.ms_profile_begin(ctx.h))
+    prove(1)
+    ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
+    shard_prof = json.loads(buf.value.decode()).get("shard", {})
     # the same trace proved UNSHARDED by rank 0 on a second context: pins the exchange path (a symmetric error - wrong chunk order in the
     # all-to-all, a mistake in the in-place all-reduce - gives every rank the same wrong root and would pass `all_ranks_same_final_root`)
     matches = None
@@ -269,7 +277,13 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
            "ranks_in_communicator": grp.world, "parallelism": how, "all_ranks_same_final_root": len(set(roots)) == 1,
            "matches_unsharded": matches,
            "collective_calls_per_rank": {n: calls[i] for i, n in enumerate(["all_to_all", "all_gather", "all_reduce_min", "all_reduce_sum"])},
-           "bytes_sent_per_rank": xchg.bytes, "proofs": steps + warmup}
+           "collective_calls_per_rank_per_proof": {n: calls[i] / max(1, steps + warmup) for i, n in enumerate(["all_to_all", "all_gather", "all_reduce_min", "all_reduce_sum"])},
+           "bytes_sent_per_rank": nbytes, "proofs": steps + warmup,
+           "distributed_rounds": dist_rounds, "rounds": cfg.rounds,
+           "partitioned_ms_estimate": shard_prof.get("partitioned_ms"), "replicated_ms_estimate": shard_prof.get("replicated_ms"),
+           "replicated_ms_note": "rank 0, one extra proof with per-launch HIP events (they add launch overhead): kernel time of launches that work on this rank's 1/world part of the proof "
+                                 "(partitioned) and of launches every rank repeats (replicated: INTT, constraint polynomials, mix, tree tops, commitments below MS_SHARD_MIN_LEAVES); "
+                                 "DESIGN.md 5"}
     xchg.close()
     ctx.close()
     return res, cfg

@@ -34,6 +34,9 @@ extern "C" {
     pub fn ms_set_shard_rccl(ctx: *mut ms_ctx, rank: c_int, world: c_int, unique_id: *const u8 /* [128] */, cap_bytes: usize) -> c_int;
     pub fn ms_rccl_selftest(ctx: *mut ms_ctx) -> c_int;
     pub fn ms_shard_stats(ctx: *mut ms_ctx, out: *mut u64 /* [8] */) -> c_int;
+    pub fn ms_shard_proof_on_root(ctx: *mut ms_ctx, on: c_int) -> c_int;
+    pub fn ms_shard_proof_is_elsewhere(ctx: *const ms_ctx) -> c_int;
+    pub fn ms_shard_round_is_distributed(ctx: *mut ms_ctx, round: c_int) -> c_int;
     // ---- src/util.rs:4-44, src/starks.rs:268-332
     pub fn ms_is_power_of_two(n: u64) -> c_int;
     pub fn ms_logarithm_of_two_k(n: u64, base: u64) -> c_long;

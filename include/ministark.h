@@ -104,8 +104,20 @@ int ms_set_shard_rccl(ms_ctx* ctx, int rank, int world, const uint8_t unique_id[
 /* the four collectives on a ONE-rank RCCL communicator with known payloads: checks the run-time binding (symbols, enums, the
  * by-value ncclUniqueId) and the stream ordering on a single GPU */
 int ms_rccl_selftest(ms_ctx* ctx);
-/* collective calls [0..3] and bytes sent [4..7] by this rank so far, per ms_xchg_op */
+/* collective calls [0..3] and bytes sent [4..7] by this rank so far, per ms_xchg_op (the gather to rank 0 is counted with the all-gathers) */
 int ms_shard_stats(ms_ctx* ctx, uint64_t out[8]);
+/* r04 - the coefficient-domain work of a sharded proof is partitioned too (env MS_SHARD_DIST=0: replicated as before): the raw-trace tree by contiguous
+ * leaf ranges (every rank holds the trace; only the subtree roots travel), and for every FRI round whose commitment is sharded the round polynomial BY
+ * COEFFICIENT RANGE - rank k holds the coefficients [k*S, (k+1)*S), S = domain / (blowup * world): the fold is local, the DEEP quotient's suffix sums take
+ * the sum over the higher ranks as carry-in (ALL_GATHER of one aggregate per rank), even(z) / odd(z) and the DEEP-ALI values of ms_eval_ext are Horner
+ * combinations of the ranks' partial sums (ALL_GATHER), the trimmed length rides on the subtree-root ALL_GATHER.  The query phase computes every quotient
+ * polynomial by coefficient range as well and ALL_GATHERs the ranks' slices of the proof - or, with ms_shard_proof_on_root(ctx, 1), GATHERs them to rank 0 only
+ * (MS_XCHG_GATHER: send = `bytes`, rank 0's recv = world * `bytes` in rank order): ms_fri_proof_size is then 0 on the other ranks.  INTT, the constraint
+ * polynomials, the mix and the commitments below MS_SHARD_MIN_LEAVES stay replicated. */
+int ms_shard_proof_on_root(ms_ctx* ctx, int on);
+int ms_shard_proof_is_elsewhere(const ms_ctx* ctx); /* 1 on a rank != 0 whose finished proof was assembled on rank 0 (ms_shard_proof_on_root) */
+/* 1 if FRI round `round` of the current proof is worked on by coefficient range (its polynomial distributed over the ranks), 0 if it is replicated */
+int ms_shard_round_is_distributed(ms_ctx* ctx, int round);
 
 /* ---- src/util.rs:4-44, src/starks.rs:268-332 (host-only config math) ----- */
 int ms_is_power_of_two(uint64_t n);

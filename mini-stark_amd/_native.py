@@ -150,6 +150,10 @@ class Context:
         self.L.ms_set_shard_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
         self.check(self.L.ms_set_shard_rccl(self.h, rank, world, unique_id, cap_bytes))
 
+    def shard_proof_on_root(self, on=True):
+        """ms_shard_proof_on_root: a sharded proof's FRI blob is assembled on rank 0 only (the other ranks send their slices and hold no proof)."""
+        self.check(self.L.ms_shard_proof_on_root(self.h, C.c_int(1 if on else 0)))
+
     def shard_stats(self):
         out = (C.c_uint64 * 8)()
         self.check(self.L.ms_shard_stats(self.h, out))
@@ -277,6 +281,8 @@ class Context:
 
     def fri_proof_read(self):
         n = self.fri_proof_size()
+        if n == 0 and self.L.ms_shard_proof_is_elsewhere(self.h) == 1:
+            return b""       # ms_shard_proof_on_root: this rank sent its slices to rank 0 and holds no proof
         buf = np.zeros(max(1, n), dtype=np.uint8)
         self.check(self.L.ms_fri_proof_read(self.h, buf.ctypes.data_as(_u8p)))
         return buf[:n].tobytes()

@@ -62,6 +62,9 @@ struct CtxBase {
   virtual int set_shard(int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) = 0;
   virtual int set_shard_rccl(int rank, int world, const u8* unique_id, size_t cap) = 0;
   virtual int shard_stats(u64* out) = 0;
+  virtual int shard_proof_on_root(int on) = 0;
+  virtual int shard_round_is_distributed(int r) = 0;
+  virtual int shard_proof_is_elsewhere() const = 0;
   virtual int shard_slice_layout(size_t* off, size_t* stride) = 0;
   virtual int rccl_selftest() = 0;
   virtual int trace_commit(const u64* trace, bool on_device, size_t N, size_t w, size_t lpn, u8* root) = 0;
@@ -276,6 +279,9 @@ template <class F> struct Ctx : CtxBase {
     a.release(); b.release();
     return rc;
   }
+  int shard_proof_on_root(int on) override { proof_root_only = on ? 1 : 0; return MS_OK; }
+  int shard_proof_is_elsewhere() const override { return (proof_root_only && sh_world > 1 && sh_rank != 0 && nrounds_done == fri_rounds && fri_rounds) ? 1 : 0; }
+  int shard_round_is_distributed(int r) override { return (r >= 0 && (size_t)r < nrounds_done && rounds[r]->dist) ? 1 : 0; }
   int shard_stats(u64* out) override { if (!out) return fail(MS_ERR_ARG, "shard_stats"); memcpy(out, xstat, sizeof xstat); return MS_OK; }
   bool shardable(size_t leaf_groups) const { return sh_world > 1 && leaf_groups >= shard_min_leaves && leaf_groups >= (size_t)sh_world * (size_t)sh_world; }
   int set_shard(int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) override {
@@ -293,7 +299,11 @@ template <class F> struct Ctx : CtxBase {
   // ---- optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
   enum { K_NTT_PASS, K_SCALE_POW, K_LEAF_HASH, K_INNER_HASH, K_TRANSPOSE, K_IO, K_LINCOMB, K_MIX, K_EVAL, K_EVAL_REDUCE, K_FOLD,
          K_SUFFIX_HORNER, K_DEGREE, K_FIND_FIRST, K_PATH, K_QUERY_POINTS, K_COUNT };
-  struct ProfRec { int kid, sub; msrt::Event* a; msrt::Event* b; double bytes; };
+  struct ProfRec { int kid, sub; msrt::Event* a; msrt::Event* b; double bytes; bool part; };
+  // sharded proofs: launches inside a PartScope work on this rank's PART of the proof (1 / world of it); everything else is replicated on every rank.
+  // ms_profile_end reports both sums: the replicated one bounds the strong scaling (bench.py: sharded.replicated_ms_estimate)
+  int part_depth = 0;
+  struct PartScope { Ctx* c; explicit PartScope(Ctx* c_) : c(c_) { c->part_depth++; } ~PartScope() { c->part_depth--; } };
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
   double next_bytes = 0;  // algorithmic bytes attributed to the next launch
@@ -310,7 +320,7 @@ template <class F> struct Ctx : CtxBase {
   template <class K> int run_coop(int kid, unsigned gx, int threads, size_t lds, const typename K::Params& p) {
     if (gx == 0) return 0;
     if (!prof_on) return msrt::launch_coop<K>(stream, gx, 1, threads, lds, p);
-    ProfRec r; r.kid = kid; r.sub = next_sub; r.bytes = next_bytes; next_bytes = 0; next_sub = 0;
+    ProfRec r; r.kid = kid; r.sub = next_sub; r.bytes = next_bytes; r.part = part_depth > 0; next_bytes = 0; next_sub = 0;
     if (msrt::event_create(&r.a) || msrt::event_create(&r.b)) return 1;
     msrt::event_record(r.a, stream);
     int e = msrt::launch_coop<K>(stream, gx, 1, threads, lds, p);
@@ -321,7 +331,7 @@ template <class F> struct Ctx : CtxBase {
   template <class K> int run(int kid, unsigned gx, unsigned gy, int threads, size_t lds, const typename K::Params& p) {
     if (gx == 0 || gy == 0) return 0;
     if (!prof_on) return msrt::launch<K>(stream, gx, gy, threads, lds, p);
-    ProfRec r; r.kid = kid; r.sub = next_sub; r.bytes = next_bytes; next_bytes = 0; next_sub = 0;
+    ProfRec r; r.kid = kid; r.sub = next_sub; r.bytes = next_bytes; r.part = part_depth > 0; next_bytes = 0; next_sub = 0;
     if (msrt::event_create(&r.a) || msrt::event_create(&r.b)) return 1;
     msrt::event_record(r.a, stream);
     int e = msrt::launch<K>(stream, gx, gy, threads, lds, p);
@@ -334,11 +344,12 @@ template <class F> struct Ctx : CtxBase {
     static const char* names[K_COUNT] = {"ntt_pass", "scale_pow", "leaf_hash", "inner_hash", "transpose_in", "io_copy", "lincomb", "mix", "eval", "eval_reduce",
                                          "fold", "suffix_horner", "degree", "find_first", "merkle_path", "query_points"};
     msrt::sync(stream);
-    double ms[K_COUNT] = {0}, by[K_COUNT] = {0}; unsigned long long cnt[K_COUNT] = {0};
+    double ms[K_COUNT] = {0}, by[K_COUNT] = {0}, ms_part = 0, ms_repl = 0; unsigned long long cnt[K_COUNT] = {0};
     std::map<int, double> sub_ms, sub_by; std::map<int, unsigned long long> sub_cnt;
     for (auto& r : prof_recs) {
       float t = 0.f; msrt::event_elapsed_ms(&t, r.a, r.b);
       ms[r.kid] += t; by[r.kid] += r.bytes; cnt[r.kid]++;
+      if (r.part) ms_part += t; else ms_repl += t;
       if (r.kid == K_NTT_PASS) { sub_ms[r.sub] += t; sub_by[r.sub] += r.bytes; sub_cnt[r.sub]++; }
       msrt::event_destroy(r.a); msrt::event_destroy(r.b);
     }
@@ -358,7 +369,8 @@ template <class F> struct Ctx : CtxBase {
       snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"alg_bytes\": %.0f}", first ? "" : ", ", name, sub_cnt[sub], kv.second, sub_by[sub]);
       j += buf; first = false;
     }
-    j += "}}";
+    j += "}";
+    { char buf[200]; snprintf(buf, sizeof buf, ", \"shard\": {\"world\": %d, \"partitioned_ms\": %.6f, \"replicated_ms\": %.6f}}", sh_world, ms_part, ms_repl); j += buf; }
     if (out && cap) { size_t n = j.size() < cap - 1 ? j.size() : cap - 1; memcpy(out, j.data(), n); out[n] = 0; }
     return 0;
   }
@@ -798,6 +810,7 @@ template <class F> struct Ctx : CtxBase {
     // the digests of slice s travel (RCCL: on the context's communication stream, ordered by events) while slice s + 1 is hashed.  MS_SHARD_SLICES (4) /
     // MS_SHARD_SLICE_MIN (1024 groups per peer and slice; below that the commitment goes out in one piece).
     const size_t S = (shard_slices > 1 && per % (size_t)shard_slices == 0 && per / (size_t)shard_slices >= shard_slice_min) ? (size_t)shard_slices : 1;
+    PartScope part(this);
     if (S == 1) {
       RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, reinterpret_cast<u32*>(xs), 0, 0, 0, lin)));
       RQ(exchange(MS_XCHG_ALL_TO_ALL, per * 32));
@@ -819,7 +832,7 @@ template <class F> struct Ctx : CtxBase {
     const size_t W = (size_t)sh_world, sub_nodes = 2 * Mloc - 1, top_nodes = 2 * W - 1;
     constexpr size_t REC = msmerkle::ShardTopKernel::REC;
     if (W * REC > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small for the subtree roots");
-    RQ(inner_levels(nodes.as<u32>(), Mloc, 2, false));
+    { PartScope part(this); RQ(inner_levels(nodes.as<u32>(), Mloc, 2, false)); }
     CK(msrt::memset_dev(xs, 0, REC, stream));
     CK(msrt::d2d(xs, nodes.as<u8>() + (sub_nodes - 1) * 32, 32, stream));
     if (shard_aux) CK(msrt::d2d(xs + 32, shard_aux, 8, stream));
@@ -841,6 +854,7 @@ template <class F> struct Ctx : CtxBase {
     if (nodes.ensure((2 * Mloc - 1 + 2 * W - 1) * 32)) return fail(MS_ERR_NOMEM, "merkle nodes");
     // group g of the launch is leaf group rank*Mloc + g (one run of Mloc groups); its digest lands at nodes[g]: the kernel indexes `nodes` by the global group
     u32* out = nodes.as<u32>() - (size_t)sh_rank * Mloc * 8;
+    PartScope part(this);
     RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, out, (size_t)sh_rank * Mloc, (u32)Mloc, 0)));
     return finish_sharded_tree(ts, nodes, Mloc);
   }
@@ -868,6 +882,7 @@ template <class F> struct Ctx : CtxBase {
   // (local_store: limb l of coefficient k*S + i at poly[l*S + i]).
   struct Round { DevBuf poly, cw, nodes; size_t cap = 0, ncoef = 0, D = 0; TreeShape ts; size_t m = 0; /* sharded: local codeword = limbs x 2 cosets x m */
                  bool dist = false, local_store = false; size_t S = 0; };
+  size_t shard_gather_chunk = 0;
   int shard_dist = 1;          // MS_SHARD_DIST=0: the coefficient-domain work of a sharded proof stays replicated on every rank (r03 behaviour; A/B and tests)
   int proof_root_only = 0;     // ms_shard_proof_on_root: the FRI proof blob is assembled on rank 0 only
   const T* lpoly(const Round* r) const { return r->local_store ? r->poly.template as<T>() : r->poly.template as<T>() + (size_t)sh_rank * r->S; }
@@ -927,6 +942,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
     if (const char* e = getenv("MS_SHARD_MIN_LEAVES")) { long v = atol(e); if (v >= 1) shard_min_leaves = (size_t)v; }
     if (const char* e = getenv("MS_SHARD_DIST")) shard_dist = atoi(e);
+    if (const char* e = getenv("MS_SHARD_GATHER_CHUNK")) { long v = atol(e); if (v >= 64) shard_gather_chunk = (size_t)v & ~(size_t)63; }
     if (const char* e = getenv("MS_SHARD_SLICES")) { int v = atoi(e); if (v >= 1 && v <= 64) shard_slices = v; }
     if (const char* e = getenv("MS_SHARD_SLICE_MIN")) { long v = atol(e); if (v >= 1) shard_slice_min = (size_t)v; }
     CK(msrt::set_device(dev));
@@ -1018,6 +1034,9 @@ template <class F> struct Ctx : CtxBase {
     typename mspoly::TransposeInKernel<F>::Params tp{dsrc, d_polys.as<T>(), N, w, N, rinv, trace_mont, reinterpret_cast<u32*>(badw)};
     CK(run<mspoly::TransposeInKernel<F>>(K_TRANSPOSE, grid1(N * w, mspoly::THREADS), 1, mspoly::THREADS, 0, tp));
     // element f of trace.get_data() = column f % w, row f / w of the column-major copy
+    // one proof over several ranks: every rank holds the whole trace, so rank k hashes the contiguous leaf groups [k*M/W, (k+1)*M/W) and only the W subtree roots travel (r04)
+    if (sh_world > 1 && shard_dist && shardable(ts.leaf_num / ts.lpn)) RQ((tree_build_sharded_contiguous<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
+    else
     RQ((tree_build<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
     trace_ts = ts;
     CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 128, badw, 4, stream));
@@ -1204,6 +1223,7 @@ template <class F> struct Ctx : CtxBase {
   int lde_compute_sharded(size_t blowup_, u64 shift) {
     const size_t c = (size_t)npolys, L_ = N * blowup_, m = L_ / (size_t)sh_world;
     if (d_lde.ensure(c * m * sizeof(T))) return fail(MS_ERR_NOMEM, "lde");
+    PartScope part(this);
     for (size_t i = 0; i < c;) {
       if (lde_linear && !poly_lin[i].idx.empty()) { i++; continue; }
       size_t j = i;
@@ -1399,7 +1419,7 @@ template <class F> struct Ctx : CtxBase {
         const int nb = (np - i0 < mspoly::MAX_POLYS) ? np - i0 : mspoly::MAX_POLYS;
         size_t off[mspoly::MAX_POLYS], cnt[mspoly::MAX_POLYS];
         for (int i = 0; i < nb; i++) { const size_t len = (i0 + i == npolys) ? validity_len : N; off[i] = lo; cnt[i] = len <= lo ? 0 : (len - lo < Sx ? len - lo : Sx); }
-        RQ((eval_views<1>(d_polys.as<T>() + (size_t)i0 * N, N, 0, 1, off, cnt, nb, zs[t], reinterpret_cast<T*>(xs) + ((size_t)t * np + i0) * E)));
+        { PartScope part(this); RQ((eval_views<1>(d_polys.as<T>() + (size_t)i0 * N, N, 0, 1, off, cnt, nb, zs[t], reinterpret_cast<T*>(xs) + ((size_t)t * np + i0) * E))); }
       }
     }
     if (tot) {
@@ -1475,7 +1495,10 @@ template <class F> struct Ctx : CtxBase {
         fp.inv2 = f_inv<F>(F::from_u64(2));
         const size_t total = m_out * fp.groups;
         next_bytes = (double)total * E * sizeof(T) * 3;   // two inputs read, one output written per element
-        CK(run<FK>(K_FOLD, grid1(total, FK::THREADS * FK::ITEMS), 1, FK::THREADS, 0, fp));
+        if (shard_next) part_depth++;
+        const int e_ = run<FK>(K_FOLD, grid1(total, FK::THREADS * FK::ITEMS), 1, FK::THREADS, 0, fp);
+        if (shard_next) part_depth--;
+        CK(e_);
         if (shard_next) RQ((tree_build_sharded<E>(r->cw.template as<T>(), m_out, 1, 2 * m_out, 2, r->ts, r->nodes)));
         else RQ((tree_build<E>(r->cw.template as<T>(), 0, 1, r->D, 1, r->ts, r->nodes)));
         return 0;
@@ -1492,7 +1515,7 @@ template <class F> struct Ctx : CtxBase {
         if (ncoef_in) RQ(gather_poly(lpoly(r), r->S, ncoef_in, d_fullpoly.as<T>(), full));
         coef = d_fullpoly.as<T>(); coef_stride = full;
       }
-      RQ(coset_eval(coef, coef_stride, ncoef_in, ctz64(r->D), F::from_u64(1), 2, r->cw.template as<T>(), 2 * m, (size_t)nonzero_limbs));
+      { PartScope part(this); RQ(coset_eval(coef, coef_stride, ncoef_in, ctz64(r->D), F::from_u64(1), 2, r->cw.template as<T>(), 2 * m, (size_t)nonzero_limbs)); }
       if (nonzero_limbs < E) CK(msrt::memset_dev(r->cw.template as<T>() + (size_t)nonzero_limbs * 2 * m, 0, (size_t)(E - nonzero_limbs) * 2 * m * sizeof(T), stream));
       RQ((tree_build_sharded<E>(r->cw.template as<T>(), m, 1, 2 * m, 2, r->ts, r->nodes)));
       return 0;
@@ -1564,7 +1587,7 @@ template <class F> struct Ctx : CtxBase {
     if (r->dist) {   // even(z), odd(z) by coefficient range: partial sums over this rank's coefficients, one all-gather, combination with z^(S/2)
       const size_t lc = lcount(r, r->ncoef);
       cnt[0] = (lc + 1) / 2; cnt[1] = lc / 2;   // (the rank's first coefficient has an even index: S is even)
-      RQ((eval_views<E>(lpoly(r), 0, lstride(r), 2, off, cnt, 2, cur_z, reinterpret_cast<T*>(xs))));
+      { PartScope part(this); RQ((eval_views<E>(lpoly(r), 0, lstride(r), 2, off, cnt, 2, cur_z, reinterpret_cast<T*>(xs)))); }
       RQ(exchange(MS_XCHG_ALL_GATHER, 2 * E * sizeof(T)));
       RQ(shard_combine_launch(0, 2 * E, 2, e_pow<F, E>(cur_z, (u64)(r->S / 2)), dst));
     } else
@@ -1581,7 +1604,7 @@ template <class F> struct Ctx : CtxBase {
   // (aggregates = input of the level above, carries = output of the level above) come from d_sh.
   typedef mspoly::SHJob<F, E> SHJ;
   typedef mspoly::SuffixHornerKernel<F, E> SHK;
-  struct SHPlan { int nl; std::vector<SHJ> agg; std::vector<SHJ> fin; bool has_top_agg = false; SHJ top_agg; size_t P = 0; };  // agg[l] for l < nl-1, fin[l] for l < nl
+  struct SHPlan { int nl; std::vector<SHJ> agg; std::vector<SHJ> fin; bool has_top_agg = false; SHJ top_agg; size_t P = 0; bool dist = false; };  // agg[l] for l < nl-1, fin[l] for l < nl
   // (P = BS^nl: where the kernel places a carry-in of the top level, in elements of the job)
   static size_t sh_scratch_elems(size_t m) {
     const size_t BS = mspoly::SH_BS;
@@ -1623,7 +1646,7 @@ template <class F> struct Ctx : CtxBase {
         if (ext_carry) { j.carry = ext_carry; j.carry_limb_stride = 1; }
       }
       if (l == 0) { j.out = out; j.out_u64 = out_u64 ? 1 : 0; j.out_limb_stride = out_limb_stride; j.out_off = out_off; j.out_stride = out_stride; j.h0 = h0; j.out_h0 = out_h0 ? 1 : 0; }
-      else { j.out = scratch + coff[l - 1]; j.out_u64 = 0; j.out_limb_stride = nbs[l - 1]; j.out_off = 0; j.out_stride = 1; j.tail_zero = 1; }
+      else { j.out = scratch + coff[l - 1]; j.out_u64 = 0; j.out_limb_stride = nbs[l - 1]; j.out_off = 0; j.out_stride = 1; j.tail_zero = ext_carry ? 2 : 1; }
       pl.fin[l] = j;
     }
     pl.P = 1; for (int l = 0; l < nl; l++) pl.P *= BS;
@@ -1672,6 +1695,7 @@ template <class F> struct Ctx : CtxBase {
     if (d_folded.ensure((Sn + 1) * E * sizeof(T)) || d_carry.ensure(4096)) return fail(MS_ERR_NOMEM, "fold");
     if (4 * E * sizeof(T) * (size_t)sh_world > xcap) return fail(MS_ERR_NOMEM, "exchange buffers");
     size_t nq_coef = 0;
+    PartScope part(this);
     if (m >= 2) {
       typename mspoly::FoldKernel<F, E>::Params fp{lpoly(pr), lstride(pr), cntp, d_folded.as<T>(), Sn, a};  // fri.rs:361-372
       CK(run<mspoly::FoldKernel<F, E>>(K_FOLD, grid1(cnt, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
@@ -1747,6 +1771,7 @@ template <class F> struct Ctx : CtxBase {
       const size_t lc = lcount(nr, nq_coef);
       if (lc) {
         typename mspoly::DegreeKernel<F, E>::Params dp{lpoly(nr), lstride(nr), lc, dres, (size_t)sh_rank * nr->S};
+        PartScope part(this);
         CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(lc, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
       }
       shard_aux = dres;
@@ -1830,8 +1855,35 @@ template <class F> struct Ctx : CtxBase {
     // ---- suffix Horner jobs: (f - g)/((x-x1)(x-x2)) = Qe(x^2) + x Qo(x^2), Qe = (even(y) - even(x3))/(y - x3) and the
     //      same for odd (fri.rs:159-167); the H_0 outputs are even(x3), odd(x3) (fri.rs:151-153)
     std::vector<T> x1h((W + 1) * nq);
-    std::vector<std::vector<SHJ>> tables;  // launch order
-    std::vector<int> table_mode;
+    std::vector<std::vector<SHJ>> tables;  // launch order: every aggregate launch (n_agg_tables of them), then - sharded proofs: behind the carry exchange - every final launch
+    std::vector<int> table_mode, table_part;   // table_part: every job of the launch works on this rank's part of a distributed round (profile: partitioned work)
+    size_t n_agg_tables = 0;
+    // ---- sharded proof, distributed rounds (r04): the quotient jobs BY COEFFICIENT RANGE.  Rank k runs every job over its own half-range [k*S/2, (k+1)*S/2) of the even / odd
+    // coefficients with the sum over the higher ranks as carry-in (ONE all-gather of the jobs' aggregates, ShardCarryKernel, which also gives every rank the H_0's),
+    // and writes its slice of every quotient polynomial - a contiguous range [t0, t1) of the record's interleaved (even, odd) coefficients - into a packed buffer;
+    // the slices are then all-gathered (or gathered to rank 0: ms_shard_proof_on_root) and copied into the blob.
+    typedef mspoly::CarryJob<F, E> CJ;
+    std::vector<CJ> carry_jobs;
+    const size_t Wr = (size_t)sh_world;
+    std::vector<size_t> sl_t0(Wr * W * nq, 0), sl_len(Wr * W * nq, 0), sl_off(Wr * W * nq, 0), sl_tot(Wr, 0);   // per rank and (window, query): slice start / length (extension elements) / packed byte offset
+    bool any_dist = false;
+    for (size_t i = 0; i <= W; i++) any_dist = any_dist || rounds[i]->dist;
+    for (size_t i = 0; i < W; i++) {
+      Round* pr = rounds[i];
+      if (!pr->dist) continue;
+      const size_t Sh = pr->S / 2;
+      for (size_t r = 0; r < Wr; r++) for (int j = 0; j < nq; j++) {
+        const size_t lo_h = r * Sh, hi_h = lo_h + Sh, q_ = qlen[i];
+        size_t t1 = 2 * (hi_h - 1); if (t1 > q_) t1 = q_;
+        size_t t0 = 2 * ((lo_h > 1 ? lo_h : 1) - 1); if (t0 > t1) t0 = t1;
+        const size_t k = (r * W + i) * nq + j;
+        sl_t0[k] = t0; sl_len[k] = t1 - t0; sl_off[k] = sl_tot[r]; sl_tot[r] += (t1 - t0) * E * 8;
+      }
+    }
+    size_t pack_max = 0;
+    for (size_t r = 0; r < Wr; r++) if (sl_tot[r] > pack_max) pack_max = sl_tot[r];
+    if (any_dist && (d_pack.ensure(pack_max + 64) || d_carry.ensure(((W + 1) * nq * 2 + 1) * E * sizeof(T)))) return fail(MS_ERR_NOMEM, "query slices");
+    if (any_dist && ((W + 1) * nq * 2 * E * sizeof(T) * Wr > xcap || xcap / Wr < 4096)) return fail(MS_ERR_NOMEM, "exchange buffers too small for the query phase");
     {
       std::vector<SHPlan> shplans;
       T* scr = d_sh.as<T>();
@@ -1848,19 +1900,62 @@ template <class F> struct Ctx : CtxBase {
           const XE X3 = e_from_base<F, E>(F::mul(x1, x1));
           for (int sgn = 0; sgn < 2; sgn++) {
             void* out = nullptr;
+            T* h0 = d_h0 + ((i * nq + j) * 2 + sgn) * E;
+            if (pr->dist) {
+              const size_t Sh = pr->S / 2, lo_h = (size_t)sh_rank * Sh, cl = mm[sgn] <= lo_h ? 0 : (mm[sgn] - lo_h < Sh ? mm[sgn] - lo_h : Sh);
+              const size_t q = carry_jobs.size();
+              T* slot_carry = d_carry.as<T>() + q * E;
+              size_t out_off = 0;
+              if (i < W) {   // the record's coefficient t sits E u64 words after coefficient t - 1: `out` is where coefficient 0 WOULD be in the packed buffer
+                const size_t k = ((size_t)sh_rank * W + i) * nq + j;
+                out = reinterpret_cast<u64*>(d_pack.as<u8>() + sl_off[k]) - sl_t0[k] * E;
+                out_off = (size_t)sgn * E + lo_h * 2 * E;
+              }
+              CJ cj; memset(&cj, 0, sizeof cj);
+              cj.agg_off = (u32)(q * E); cj.has_first = 0; cj.zA = e_one<F, E>(); cj.zB = e_pow<F, E>(X3, (u64)Sh);
+              cj.carry_out = slot_carry; cj.tail_out = nullptr; cj.h0_out = h0; cj.scale = e_zero<F, E>();
+              if (cl) {
+                SHPlan pl = sh_plan(lpoly(pr), lstride(pr), sgn, 2, cl, X3, out, true, 1, out_off, 2 * E, nullptr, scr, slot_carry, reinterpret_cast<T*>(xs) + q * E, sh_rank > 0);
+                cj.scale = carry_scale(X3, cl, pl.P);
+                pl.dist = true;
+                shplans.push_back(pl);
+                scr += sh_scratch_elems(cl);
+              }
+              carry_jobs.push_back(cj);
+              continue;
+            }
             if (i < W) out = blob + rec_off[i * nq + j] + (6 * E + 1) * 8;
-            shplans.push_back(sh_plan(pr->poly.template as<T>(), pr->cap, sgn, 2, mm[sgn], X3, out, true, 1, (size_t)sgn * E, 2 * E,
-                                    d_h0 + ((i * nq + j) * 2 + sgn) * E, scr));
+            shplans.push_back(sh_plan(pr->poly.template as<T>(), pr->cap, sgn, 2, mm[sgn], X3, out, true, 1, (size_t)sgn * E, 2 * E, h0, scr));
             scr += sh_scratch_elems(mm[sgn]);
           }
         }
       }
       int max_nl = 1;
       for (auto& pl : shplans) if (pl.nl > max_nl) max_nl = pl.nl;
-      // group by level count so that every launch is homogeneous: aggregates bottom-up, finals top-down
+      // group by level count so that every launch is homogeneous: aggregates bottom-up (the ranks' top-level aggregates last), finals top-down
       for (int nl = 1; nl <= max_nl; nl++) {
-        for (int l = 0; l + 1 < nl; l++) { std::vector<SHJ> t; for (auto& pl : shplans) if (pl.nl == nl) t.push_back(pl.agg[l]); if (!t.empty()) { tables.push_back(t); table_mode.push_back(0); } }
-        for (int l = nl - 1; l >= 0; l--) { std::vector<SHJ> t; for (auto& pl : shplans) if (pl.nl == nl) t.push_back(pl.fin[l]); if (!t.empty()) { tables.push_back(t); table_mode.push_back(1); } }
+        for (int l = 0; l + 1 < nl; l++) { std::vector<SHJ> t; bool ad = true; for (auto& pl : shplans) if (pl.nl == nl) { t.push_back(pl.agg[l]); ad = ad && pl.dist; } if (!t.empty()) { tables.push_back(t); table_mode.push_back(0); table_part.push_back(ad); } }
+        { std::vector<SHJ> t; for (auto& pl : shplans) if (pl.nl == nl && pl.has_top_agg) t.push_back(pl.top_agg); if (!t.empty()) { tables.push_back(t); table_mode.push_back(0); table_part.push_back(1); } }
+      }
+      n_agg_tables = tables.size();
+      for (int nl = 1; nl <= max_nl; nl++)
+        for (int l = nl - 1; l >= 0; l--) { std::vector<SHJ> t; bool ad = true; for (auto& pl : shplans) if (pl.nl == nl) { t.push_back(pl.fin[l]); ad = ad && pl.dist; } if (!t.empty()) { tables.push_back(t); table_mode.push_back(1); table_part.push_back(ad); } }
+    }
+    // ---- the slices' way into the blob: chunks of at most xcap / world bytes per rank and exchange
+    std::vector<msmerkle::CopyJob> unp; std::vector<size_t> unp_first, unp_cnt, chunk_c0, chunk_len;
+    if (any_dist && pack_max) {
+      size_t Cb = (pack_max < ((xcap / Wr) & ~(size_t)63)) ? pack_max : ((xcap / Wr) & ~(size_t)63);
+      if (shard_gather_chunk && shard_gather_chunk < Cb) Cb = shard_gather_chunk;   // MS_SHARD_GATHER_CHUNK (tests): several exchanges at small sizes
+      for (size_t c0 = 0; c0 < pack_max; c0 += Cb) {
+        const size_t len = pack_max - c0 < Cb ? pack_max - c0 : Cb;
+        chunk_c0.push_back(c0); chunk_len.push_back(len); unp_first.push_back(unp.size());
+        for (size_t r = 0; r < Wr; r++) for (size_t i = 0; i < W; i++) for (int j = 0; j < nq; j++) {
+          const size_t k = (r * W + i) * nq + j, b0 = sl_off[k], b1 = b0 + sl_len[k] * E * 8;
+          const size_t p0 = b0 > c0 ? b0 : c0, p1 = b1 < c0 + len ? b1 : c0 + len;
+          if (p0 >= p1) continue;
+          unp.push_back(msmerkle::CopyJob{xr + r * len + (p0 - c0), blob + rec_off[i * nq + j] + (6 * E + 1) * 8 + sl_t0[k] * E * 8 + (p0 - b0), p1 - p0});
+        }
+        unp_cnt.push_back(unp.size() - unp_first.back());
       }
     }
     // ---- find-first and path jobs
@@ -1901,6 +1996,9 @@ template <class F> struct Ctx : CtxBase {
     const size_t off_rec = bytes; bytes += rec_off.size() * sizeof(size_t);
     const size_t off_ql = bytes; bytes += qlen.size() * 8;
     const size_t off_x1 = bytes; bytes += x1h.size() * sizeof(T);
+    bytes = (bytes + 15) & ~(size_t)15;
+    const size_t off_cr = bytes; bytes += carry_jobs.size() * sizeof(CJ);
+    const size_t off_un = bytes; bytes += unp.size() * sizeof(msmerkle::CopyJob);
     u8* tab;
     RQ(tabs_host(bytes + 8, &tab));
     for (size_t k = 0; k < tables.size(); k++) memcpy(tab + toff[k], tables[k].data(), tables[k].size() * sizeof(SHJ));
@@ -1911,16 +2009,48 @@ template <class F> struct Ctx : CtxBase {
     if (!rec_off.empty()) memcpy(tab + off_rec, rec_off.data(), rec_off.size() * sizeof(size_t));
     memcpy(tab + off_ql, qlen.data(), qlen.size() * 8);
     memcpy(tab + off_x1, x1h.data(), x1h.size() * sizeof(T));
+    if (!carry_jobs.empty()) memcpy(tab + off_cr, carry_jobs.data(), carry_jobs.size() * sizeof(CJ));
+    if (!unp.empty()) memcpy(tab + off_un, unp.data(), unp.size() * sizeof(msmerkle::CopyJob));
     if (d_tabs.ensure(bytes + 8)) return fail(MS_ERR_NOMEM, "query tables");
     CK(msrt::h2d(d_tabs.p, tab, bytes + 8, stream));   // page-locked source: no synchronisation here (this stage ends with one; the area is next written by the next proof)
     const u8* dt = d_tabs.as<u8>();
     // ---- launches
+    if (!carry_jobs.empty()) CK(msrt::memset_dev(xs, 0, carry_jobs.size() * E * sizeof(T), stream));   // aggregates of the jobs this rank has no coefficients for
     for (size_t k = 0; k < tables.size(); k++) {
+      if (k == n_agg_tables && !carry_jobs.empty()) {   // every aggregate is in the send buffer: one all-gather, then the carry-ins of this rank's jobs and every job's H_0
+        RQ(exchange(MS_XCHG_ALL_GATHER, carry_jobs.size() * E * sizeof(T)));
+        typedef mspoly::ShardCarryKernel<F, E> CKn;
+        typename CKn::Params cp; memset(&cp, 0, sizeof cp);
+        cp.jobs = reinterpret_cast<const CJ*>(dt + off_cr); cp.njobs = (u32)carry_jobs.size(); cp.W = (u32)sh_world; cp.rank = (u32)sh_rank;
+        cp.gathered = reinterpret_cast<const T*>(xr); cp.rank_stride = carry_jobs.size() * E;
+        CK(run<CKn>(K_SUFFIX_HORNER, grid1(carry_jobs.size(), CKn::THREADS), 1, CKn::THREADS, 0, cp));
+      }
       size_t maxnb = 1;
       for (auto& j : tables[k]) { size_t nb = j.m ? (j.m + mspoly::SH_BS - 1) / mspoly::SH_BS : 1; if (nb > maxnb) maxnb = nb; }
       typename SHK::Params p; p.jobs = reinterpret_cast<const SHJ*>(dt + toff[k]); p.final_mode = table_mode[k];
       memset(&p.inline_job, 0, sizeof p.inline_job);
-      CK(run<SHK>(K_SUFFIX_HORNER, (unsigned)maxnb, (unsigned)tables[k].size(), SHK::THREADS, SHK::lds_bytes(), p));
+      if (table_part[k]) part_depth++;
+      const int e_ = run<SHK>(K_SUFFIX_HORNER, (unsigned)maxnb, (unsigned)tables[k].size(), SHK::THREADS, SHK::lds_bytes(), p);
+      if (table_part[k]) part_depth--;
+      CK(e_);
+    }
+    if (n_agg_tables == tables.size() && !carry_jobs.empty()) {   // (no job on this rank at all: the exchange still has to happen - the other ranks are in it)
+      RQ(exchange(MS_XCHG_ALL_GATHER, carry_jobs.size() * E * sizeof(T)));
+      typedef mspoly::ShardCarryKernel<F, E> CKn;
+      typename CKn::Params cp; memset(&cp, 0, sizeof cp);
+      cp.jobs = reinterpret_cast<const CJ*>(dt + off_cr); cp.njobs = (u32)carry_jobs.size(); cp.W = (u32)sh_world; cp.rank = (u32)sh_rank;
+      cp.gathered = reinterpret_cast<const T*>(xr); cp.rank_stride = carry_jobs.size() * E;
+      CK(run<CKn>(K_SUFFIX_HORNER, grid1(carry_jobs.size(), CKn::THREADS), 1, CKn::THREADS, 0, cp));
+    }
+    for (size_t c = 0; c < chunk_c0.size(); c++) {   // the ranks' slices of the quotient polynomials into the blob
+      CK(msrt::d2d(xs, d_pack.as<u8>() + chunk_c0[c], chunk_len[c], stream));
+      RQ(exchange(proof_root_only ? MS_XCHG_GATHER : MS_XCHG_ALL_GATHER, chunk_len[c]));
+      if (unp_cnt[c] && (!proof_root_only || sh_rank == 0)) {
+        size_t maxw = 1;
+        for (size_t u = 0; u < unp_cnt[c]; u++) { const size_t wgs = (unp[unp_first[c] + u].bytes / 8 + msmerkle::CopyRangesKernel::WORDS - 1) / msmerkle::CopyRangesKernel::WORDS; if (wgs > maxw) maxw = wgs; }
+        msmerkle::CopyRangesKernel::Params up{reinterpret_cast<const msmerkle::CopyJob*>(dt + off_un) + unp_first[c], (u32)unp_cnt[c]};
+        CK(run<msmerkle::CopyRangesKernel>(K_IO, (unsigned)maxw, (unsigned)unp_cnt[c], msmerkle::CopyRangesKernel::THREADS, 0, up));
+      }
     }
     if (W) {
       typename mspoly::QueryPointsKernel<F, E>::Params qp{d_h0, reinterpret_cast<const T*>(dt + off_x1), reinterpret_cast<const u64*>(dt + off_ql), (int)W, nq, blob,
@@ -1932,7 +2062,10 @@ template <class F> struct Ctx : CtxBase {
       for (size_t i = 0; i < W; i++) if (rounds[i]->D <= ((size_t)1 << 16)) { first_small = i; break; }
       for (size_t i = 0; i < first_small; i++) {
         typename mspoly::FindFirstKernel<F, E>::Params fp; fp.jobs = nullptr; fp.inline_job = fjobs[i];
-        CK(run<mspoly::FindFirstKernel<F, E>>(K_FIND_FIRST, grid1(rounds[i]->D, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
+        if (rounds[i]->ts.sharded) part_depth++;
+        const int e_ = run<mspoly::FindFirstKernel<F, E>>(K_FIND_FIRST, grid1(rounds[i]->ts.sharded ? 2 * rounds[i]->m : rounds[i]->D, mspoly::THREADS), 1, mspoly::THREADS, 0, fp);
+        if (rounds[i]->ts.sharded) part_depth--;
+        CK(e_);
       }
       if (first_small < W) {
         typename mspoly::FindFirstKernel<F, E>::Params fp; fp.jobs = reinterpret_cast<const FJ*>(dt + off_f) + first_small; fp.inline_job = fjobs[first_small];
@@ -1963,7 +2096,7 @@ template <class F> struct Ctx : CtxBase {
       const unsigned long long* hidx = reinterpret_cast<const unsigned long long*>(pinned);
       for (size_t t = 0; t < W * nq * 2; t++) if (hidx[t] == ~0ULL) return fail(MS_ERR_LEAF_NOT_FOUND, "leaf is not included in the tree");
     } else CK(msrt::sync(stream));
-    blob_size = pos;
+    blob_size = (proof_root_only && sh_world > 1 && sh_rank != 0) ? 0 : pos;   // ms_shard_proof_on_root: the blob is whole on rank 0 only
     return MS_OK;
   }
   size_t fri_proof_size() const override { return blob_size; }
@@ -2182,6 +2315,9 @@ int ms_set_shard_rccl(ms_ctx* ctx, int rank, int world, const uint8_t unique_id[
 }
 int ms_rccl_selftest(ms_ctx* ctx) { if (!ctx) return MS_ERR_ARG; B(ctx)->bind_device(); return B(ctx)->rccl_selftest(); }
 int ms_shard_stats(ms_ctx* ctx, uint64_t out[8]) { if (!ctx) return MS_ERR_ARG; return B(ctx)->shard_stats(out); }
+int ms_shard_round_is_distributed(ms_ctx* ctx, int round) { if (!ctx) return MS_ERR_ARG; return B(ctx)->shard_round_is_distributed(round); }
+int ms_shard_proof_is_elsewhere(const ms_ctx* ctx) { return ctx ? B(ctx)->shard_proof_is_elsewhere() : MS_ERR_ARG; }
+int ms_shard_proof_on_root(ms_ctx* ctx, int on) { if (!ctx) return MS_ERR_ARG; return B(ctx)->shard_proof_on_root(on); }
 int ms_shard_slice_layout(ms_ctx* ctx, size_t* offset, size_t* stride) { if (!ctx) return MS_ERR_ARG; return B(ctx)->shard_slice_layout(offset, stride); }
 int ms_synchronize(ms_ctx* ctx) { if (!ctx) return MS_ERR_ARG; B(ctx)->bind_device(); return B(ctx)->synchronize(); }
 

@@ -302,7 +302,8 @@ template <class F, int E> struct FoldKernel {
 //               writes H_j for j >= 1 to out[l*out_limb_stride + out_off + (j-1)*out_stride]
 //               (u64 or T elements, out == null: discarded) and H_0 to h0[l];
 //               tail_zero: also stores 0 at out index m-1 (the output is the carry array of
-//               the level below, whose last block has no carry-in).
+//               the level below, whose last block has no carry-in); tail_zero == 2: stores the
+//               carry-in propagated to position m instead (jobs with a carry-in at the top level).
 // zpow[i] = z^(SEG * 2^i), i < 9.
 constexpr int SH_SEG = 8;
 constexpr int SH_BS = THREADS * SH_SEG;
@@ -406,8 +407,12 @@ template <class F, int E> struct SuffixHornerKernel {
       }
       if (jb.tail_zero && jb.out && j + 1 == jb.m) {
         for (int l = 0; l < E; l++) {
+          // tail_zero == 2 (a job with an external carry-in at its top level): the last block of the level below is not the end of the vector - its carry-in is the
+          // suffix sum at position m of THIS level = the block's carry-in propagated through the zero padding behind element m - 1 (fbuf holds H at every position)
+          T tv = 0;
+          if (jb.tail_zero == 2) tv = (i + 1 < SH_BS) ? fbuf[(size_t)l * SH_BS + i + 1] : sc[(size_t)l * (THREADS + 1) + THREADS];
           const size_t o = (size_t)l * jb.out_limb_stride + jb.out_off + j * jb.out_stride;
-          if (jb.out_u64) reinterpret_cast<u64*>(jb.out)[o] = 0; else reinterpret_cast<T*>(jb.out)[o] = 0;
+          if (jb.out_u64) reinterpret_cast<u64*>(jb.out)[o] = F::to_u64(tv); else reinterpret_cast<T*>(jb.out)[o] = tv;
         }
       }
     }

@@ -128,6 +128,19 @@ class ShardExchange:
                 if self.send.is_cuda:
                     torch.cuda.synchronize()
                 return 0
+            if op == 5:      # gather to rank 0: chunk r of rank 0's receive buffer from rank r (ms_shard_proof_on_root)
+                self.calls[1] += 1
+                a = self.send[:nbytes].cpu() if self.staged else self.send[:nbytes]
+                if self.g.rank == 0:
+                    parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(W)]
+                    d.gather(a.cpu(), parts, dst=0)
+                    self.recv[: nbytes * W].copy_(torch.cat(parts))
+                else:
+                    d.gather(a.cpu(), None, dst=0)
+                    self.bytes += nbytes
+                if self.send.is_cuda:
+                    torch.cuda.synchronize()
+                return 0
             self.calls[op] += 1
             self.bytes += nbytes * (W if op == 0 else 1)
             if op == 0:      # all-to-all of W chunks

@@ -17,8 +17,9 @@ from oracle import oracle as orc  # noqa: E402
 field, log_n, blowup = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 os.environ["MS_SHARD_MIN_LEAVES"] = sys.argv[4] if len(sys.argv) > 4 else "16"
 mode = sys.argv[5] if len(sys.argv) > 5 else ""
-on_gpu = mode in ("gpu", "gpu-self")   # the real HIP library, all ranks on GPU 0, payloads staged through host tensors for gloo
-self_check = mode == "gpu-self"        # sizes beyond the oracle's reach: compare with an UNSHARDED proof of the same library instead
+modes = set(mode.split(","))           # several at once: "gpu,root-only"
+on_gpu = bool(modes & {"gpu", "gpu-self"})   # the real HIP library, all ranks on GPU 0, payloads staged through host tensors for gloo
+self_check = "gpu-self" in modes       # sizes beyond the oracle's reach: compare with an UNSHARDED proof of the same library instead
 grp = Group("gloo")
 N = 1 << log_n
 cap = 32 * N * blowup // grp.world + (1 << 20)  # leaf digests of the largest commitment / world + query-phase paths
@@ -32,18 +33,27 @@ else:
 trace = fibonacci_trace_fast(field, N)
 if log_n >= 16:  # full-size comparisons: OpenMP over the oracle's independent loops (every rank runs its own oracle)
     orc.set_threads(max(1, min(8, len(os.sched_getaffinity(0)) // grp.world)))
-got = pc.drive(ctx, field, trace, blowup, 2, seed=11, read_big=False)
+root_only = "root-only" in modes        # ms_shard_proof_on_root: only rank 0 ends up with the FRI proof
+base_z = (1, 2) if "base-z" in modes else ()   # DEEP points in the base field in the first rounds (distributed polynomials: the transform fallback gathers them)
+if root_only:
+    ctx.shard_proof_on_root(True)
+got = pc.drive(ctx, field, trace, blowup, 2, seed=11, read_big=False, base_field_z_rounds=base_z)
 if self_check:
-    want = pc.drive(ms.Context(field), field, trace, blowup, 2, seed=11, read_big=False)
+    want = pc.drive(ms.Context(field), field, trace, blowup, 2, seed=11, read_big=False, base_field_z_rounds=base_z)
 else:
-    want = pc.drive(orc.Session(field), field, trace, blowup, 2, seed=11, read_big=False)
+    want = pc.drive(orc.Session(field), field, trace, blowup, 2, seed=11, read_big=False, base_field_z_rounds=base_z)
 assert len(got) == len(want)
 for (ka, va), (kb, vb) in zip(got, want):
+    if root_only and ka == "fri_proof" and grp.rank != 0:
+        assert va == b"", f"rank {grp.rank} holds a proof although it is assembled on rank 0 only"
+        continue
     assert ka == kb and va == vb, f"rank {grp.rank}: stage output {ka} differs from the oracle"
 # the distributed parts are not readable in shard mode
 assert ctx.L.ms_lde_read(ctx.h, None) != 0
 grp.barrier()
 if grp.rank == 0:
-    print(json.dumps({"world": grp.world, "calls": xchg.calls, "bytes": xchg.bytes, "stages": len(got), "slices": xchg.slices}), flush=True)
+    import ctypes as C
+    dr = sum(1 for i in range(64) if ctx.L.ms_shard_round_is_distributed(ctx.h, C.c_int(i)) == 1)
+    print(json.dumps({"world": grp.world, "calls": xchg.calls, "bytes": xchg.bytes, "stages": len(got), "slices": xchg.slices, "dist_rounds": dr, "root_only": root_only}), flush=True)
 xchg.close()
 grp.close()

@@ -33,7 +33,8 @@ def check(res, world):
     assert sh["ranks_in_communicator"] == world and sh["all_ranks_same_final_root"]
     assert sh["matches_unsharded"]["all"], sh["matches_unsharded"]
     cc = sh["collective_calls_per_rank"]
-    assert cc["all_to_all"] >= 3 and cc["all_gather"] == cc["all_to_all"]   # the LDE and the large FRI rounds went through the digest exchange
+    assert cc["all_to_all"] >= 3 and cc["all_gather"] > cc["all_to_all"]   # the LDE and the large FRI rounds went through the digest exchange; r04: the coefficient-domain work adds small all-gathers
+    assert sh["distributed_rounds"] >= 2 and sh["replicated_ms_estimate"] is not None and sh["partitioned_ms_estimate"] is not None
 
 
 ARGV = ["--emu", "--log-rows", "7", "--steps", "1", "--warmup", "1", "--inflight", "1", "--shard-log-rows", "9", "--shard-steps", "1"]

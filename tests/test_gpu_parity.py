@@ -209,8 +209,8 @@ def test_merkle_prove_by_value(mk, field, ext, lpn, n):
     pc.case_merkle_prove(mk, field, n, ext, lpn)
 
 
-@pytest.mark.parametrize("world,field,log_n", [(2, 0, 12), (4, 1, 11)])
-def test_sharded_proof_on_gpu(world, field, log_n):
+@pytest.mark.parametrize("world,field,log_n,mode", [(2, 0, 12, "gpu"), (4, 1, 11, "gpu"), (2, 0, 16, "gpu"), (4, 0, 15, "gpu,root-only"), (2, 1, 13, "gpu,base-z")])
+def test_sharded_proof_on_gpu(world, field, log_n, mode):
     """ms_set_shard on the real HIP kernels: `world` ranks share this box's GPU (gloo, payloads staged through host
     memory), each proves its share of ONE proof; every rank checks all outputs against the oracle (tests/shard_worker.py)."""
     import json
@@ -218,12 +218,13 @@ def test_sharded_proof_on_gpu(world, field, log_n):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29950 + world), os.path.join(here, "shard_worker.py"), str(field), str(log_n), "8", "64", "gpu"]
+           "--master-port", str(29950 + world), os.path.join(here, "shard_worker.py"), str(field), str(log_n), "8", "64", mode]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     calls = {int(k): v for k, v in res["calls"].items()}
     assert res["world"] == world and calls[0] >= 3 and calls[2] == 1 and calls[3] == 1
+    assert res["dist_rounds"] >= 2 and calls[1] > calls[0]    # r04: the coefficient-domain work is partitioned too (distributed round polynomials; multi-level scans at 2^15+ rows)
 
 
 @pytest.mark.parametrize("field,log_n", [(0, 10), (1, 9), (0, 20), (1, 18)])
@@ -260,7 +261,9 @@ def test_sharded_full_size_matches_oracle():
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     calls = {int(k): v for k, v in res["calls"].items()}
-    assert calls[0] == 9 and calls[1] == 9 and calls[2] == 1 and calls[3] == 1
+    # 9 digest all-to-alls (LDE + the eight largest FRI rounds); r04: besides their 9 root all-gathers, the raw-trace tree's, the DEEP-ALI partial sums, two per distributed
+    # round (DEEP partial sums, scan carries), the hand-over of the first replicated round polynomial, the query jobs' aggregates and the proof slices
+    assert calls[0] == 9 and calls[1] >= 9 + 2 + 2 * 8 + 2 and calls[2] == 1 and calls[3] == 1 and res["dist_rounds"] == 8
 
 
 @pytest.mark.parametrize("field", [0, 1])

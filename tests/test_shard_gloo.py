@@ -12,11 +12,11 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_world(world, field, log_n, blowup, min_leaves, port, env=None):
+def run_world(world, field, log_n, blowup, min_leaves, port, env=None, mode=""):
     subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", os.path.join(HERE, "..", "oracle")], stdout=subprocess.DEVNULL)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(HERE, "shard_worker.py"), str(field), str(log_n), str(blowup), str(min_leaves)]
+           "--master-port", str(port), os.path.join(HERE, "shard_worker.py"), str(field), str(log_n), str(blowup), str(min_leaves)] + ([mode] if mode else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -27,9 +27,35 @@ def test_sharded_proof_matches_oracle(world, field, log_n, blowup):
     res = run_world(world, field, log_n, blowup, 16, 29800 + world * 10 + field * 3 + log_n)
     assert res["world"] == world
     calls = {int(k): v for k, v in res["calls"].items()}
-    # the LDE commitment and the large FRI rounds went through the digest all-to-all + root all-gather,
-    # the query phase through one MIN and one SUM all-reduce
-    assert calls[0] >= 3 and calls[1] == calls[0] and calls[2] == 1 and calls[3] == 1
+    # the LDE commitment and the large FRI rounds went through the digest all-to-all + root all-gather, the query phase through one MIN and one SUM
+    # all-reduce; r04: the coefficient-domain work is partitioned too - per distributed round two more small all-gathers (DEEP partial sums, the suffix
+    # scan's carries), one for the raw-trace tree's roots, one for the DEEP-ALI partial sums, one for the query jobs' aggregates, and the proof slices
+    assert calls[0] >= 3 and calls[1] >= calls[0] + 2 * (calls[0] - 1) + 3 and calls[2] == 1 and calls[3] == 1
+    assert res["dist_rounds"] >= 2
+
+
+@pytest.mark.parametrize("world,field,log_n", [(2, 0, 8), (4, 1, 8)])
+def test_sharded_proof_with_replicated_coefficient_work(world, field, log_n):
+    """MS_SHARD_DIST=0: the r03 scheme (only the evaluation-domain work of the commitments is partitioned) still gives the oracle's bytes."""
+    res = run_world(world, field, log_n, 8, 16, 29600 + world * 10 + field * 3 + log_n, env={"MS_SHARD_DIST": "0"})
+    calls = {int(k): v for k, v in res["calls"].items()}
+    assert calls[0] >= 3 and calls[1] == calls[0] and calls[2] == 1 and calls[3] == 1 and res["dist_rounds"] == 0
+
+
+@pytest.mark.parametrize("world,field,log_n", [(2, 0, 8), (4, 0, 9), (8, 1, 9)])
+def test_sharded_proof_assembled_on_rank0_only(world, field, log_n):
+    """ms_shard_proof_on_root: the ranks' slices of the quotient polynomials are GATHERED to rank 0 (MS_XCHG_GATHER) instead of all-gathered; rank 0's proof
+    equals the oracle's, the other ranks hold none; every other stage output is still identical on every rank."""
+    res = run_world(world, field, log_n, 8, 16, 29500 + world * 10 + field * 3 + log_n, mode="root-only")
+    assert res["world"] == world and res["root_only"] is True
+
+
+@pytest.mark.parametrize("world,field,log_n", [(2, 0, 8), (4, 1, 8)])
+def test_sharded_proof_with_base_field_deep_points(world, field, log_n):
+    """A DEEP point in the base field makes the evaluation-domain fold impossible (x^2 - z can vanish): the codeword of that round comes from a transform of
+    the round polynomial, which for a DISTRIBUTED polynomial means gathering its parts first (round_commit's fallback)."""
+    res = run_world(world, field, log_n, 8, 16, 29400 + world * 10 + field * 3 + log_n, mode="base-z")
+    assert res["world"] == world
 
 
 def test_small_proof_stays_replicated():
@@ -46,3 +72,12 @@ def test_sliced_digest_exchange_matches_oracle(world, field, log_n, slices):
     res = run_world(world, field, log_n, 8, 16, 29700 + world * 10 + field * 3 + log_n, env={"MS_SHARD_SLICES": str(slices), "MS_SHARD_SLICE_MIN": "1"})
     calls = {int(k): v for k, v in res["calls"].items()}
     assert res["slices"] >= slices and calls[0] >= 1 and calls[1] >= calls[0]
+
+
+@pytest.mark.parametrize("world,field,log_n,env,mode", [(2, 0, 14, {}, ""), (2, 1, 14, {}, ""), (4, 0, 14, {"MS_SHARD_GATHER_CHUNK": "4096"}, ""),
+                                                       (2, 0, 12, {"MS_SHARD_GATHER_CHUNK": "1024"}, "root-only"), (8, 0, 13, {"MS_SHARD_GATHER_CHUNK": "8192"}, "")])
+def test_sharded_multilevel_scans_and_chunked_proof_gather(world, field, log_n, env, mode):
+    """Ranks whose coefficient ranges exceed one block of the suffix scan (2048 elements: the carry-in from the higher ranks then travels down the scan's levels), and
+    proof slices that cross the exchange buffer in several pieces (MS_SHARD_GATHER_CHUNK forces small pieces), all-gathered and gathered to rank 0."""
+    res = run_world(world, field, log_n, 8, 16, 29300 + world * 10 + field * 3 + log_n + (5 if mode else 0), env=env, mode=mode)
+    assert res["world"] == world and res["dist_rounds"] >= 8

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""What ONE rank of a W-rank sharded proof computes, measured on one GPU: the context is rank W-1 of W with a STUB exchange (every collective returns the rank's own
+payload in every peer's place - no peers exist), so the kernels run on operands of the right SIZES but wrong VALUES; the proof itself is garbage (the query phase
+ends with "leaf not found", after all its work).  Gives, per world size: wall time of the rank's proof, kernel time partitioned / replicated (HIP events per launch,
+ms_profile), collective calls - next to the unsharded proof on the same GPU.  Strong-scaling bound = unsharded time / (rank time + link time of the exchanges).
+  python3 tools/shard_rank_probe.py --log-rows 24 --worlds 2 4 8"""
+import argparse, ctypes as C, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import mini_stark_amd as ms
+from mini_stark_amd.stark import StarkConfig, fibonacci_air
+from mini_stark_amd.host import HostStark
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--log-rows", type=int, default=20)
+ap.add_argument("--worlds", type=int, nargs="+", default=[2, 4, 8])
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--dist", type=int, nargs="+", default=[1, 0], help="MS_SHARD_DIST values to compare (1: coefficient-domain work partitioned, 0: replicated as in r03)")
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+N = 1 << args.log_rows
+blowup = 8
+
+
+class Stub:
+    def __init__(self, ctx, rank, world, cap):
+        self.ctx, self.W = ctx, world
+        self.send = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.recv = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.calls = {}
+        ctx.set_shard(rank, world, self.send.data_ptr(), self.recv.data_ptr(), cap, self.cb)
+
+    def cb(self, op, n):
+        self.calls[op] = self.calls.get(op, 0) + 1
+        W = self.W
+        if op == 0:
+            self.recv[: n * W].copy_(self.send[: n * W])
+        elif op == 1:
+            self.recv[: n * W].view(W, n).copy_(self.send[:n].unsqueeze(0).expand(W, n))
+        elif op == 4:
+            off, stride = C.c_size_t(0), C.c_size_t(0)
+            self.ctx.L.ms_shard_slice_layout(self.ctx.h, C.byref(off), C.byref(stride))
+            for p in range(W):
+                a = off.value + p * stride.value
+                self.recv[a: a + n].copy_(self.send[a: a + n])
+        torch.cuda.synchronize()
+        return 0
+
+
+def one(world, dist):
+    os.environ["MS_SHARD_DIST"] = str(dist)
+    ctx = ms.Context(0)
+    stub = None
+    if world > 1:
+        stub = Stub(ctx, world - 1, world, 32 * N * blowup // world + (4 << 20))
+    tt = fibonacci_air(ctx, N - 1)
+    hs = HostStark(ctx, 20, blowup, N - 1, tt.constrain_number())
+    d_trace = torch.from_numpy(tt.data.view(np.int64)).to(dev)
+    ok = (0,) if world == 1 else (0, ms.ERR_LEAF_NOT_FOUND)
+    def prove():
+        rc = hs.prove_raw(tt, trace_device_ptr=d_trace.data_ptr(), read_fri_proof=False)
+        assert rc in ok, (rc, ctx.last_error())
+    prove()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(args.reps):
+        t0 = time.perf_counter(); prove(); ts.append((time.perf_counter() - t0) * 1e3)
+    buf = C.create_string_buffer(1 << 14)
+    ctx.check(ctx.L.ms_profile_begin(ctx.h)); prove(); ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
+    prof = json.loads(buf.value.decode())
+    sh = prof.pop("shard", {})
+    prof.pop("ntt_pass_variants", None)
+    res = {"world": world, "shard_dist": dist, "log_rows": args.log_rows, "ms_wall_min": round(min(ts), 3), "ms_wall_all": [round(t, 3) for t in ts],
+           "kernel_ms_total": round(sum(v["ms"] for v in prof.values()), 3), "partitioned_ms": sh.get("partitioned_ms"), "replicated_ms": sh.get("replicated_ms"),
+           "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]},
+           "launches": sum(v["launches"] for v in prof.values()), "collective_calls": stub.calls if stub else {}}
+    if stub:
+        ctx.set_shard(0, 1, 0, 0, 0, None)
+    ctx.close()
+    return res
+
+
+base = one(1, 1)
+print(json.dumps(base), flush=True)
+for w in args.worlds:
+    for d in args.dist:
+        r = one(w, d)
+        r["speedup_bound_no_link_time"] = round(base["ms_wall_min"] / r["ms_wall_min"], 3)
+        print(json.dumps(r), flush=True)
