@@ -263,3 +263,84 @@ def test_prove_other_blowups(mk, field, log_n, blowup):
 @pytest.mark.parametrize("field,log_n,steps", [(0, 6, 40), (1, 7, 70), (0, 8, 128)])
 def test_prove_several_padding_rows(mk, field, log_n, steps):
     pc.case_prove(mk, field, log_n, 8, read_big=False, steps=steps)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_c_abi_never_unwinds(field):
+    """SURVEY 8(b) "never unwind" (VERDICT r3 #5): every entry point of libministark runs inside a guard that turns std::bad_alloc into MS_ERR_NOMEM (anything else
+    into MS_ERR_HIP).  The emulation build's operator new (hidden: this library's allocations only) can be armed to fail on its N-th call: a whole proof is driven
+    with the failure placed at EVERY allocation it makes, one after the other - the stage that hits it must return a negative code (never abort the process, never
+    unwind into ctypes), the stages before it succeed, and afterwards the same context still produces the oracle's proof."""
+    import ctypes as C
+    import numpy as np
+    from common import MODULUS, EXT, SplitMix64, fibonacci_trace, fibonacci_closures
+    from oracle import oracle as orc
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+    L = C.CDLL(EMU)
+    L.ms_emu_alloc_count.restype = C.c_long
+    L.ms_emu_fail_alloc_after.argtypes = [C.c_long]
+    p, e = MODULUS[field], EXT[field]
+    N, blowup = 16, 4
+    trace = fibonacci_trace(field, N)
+    omega = orc.root_of_unity(field, N)
+    rounds = 6
+    u64p = C.POINTER(C.c_uint64)
+
+    def stages(h):
+        """the reference's prove sequence as raw C calls: yields (name, rc)"""
+        rng = SplitMix64(5)
+        root = (C.c_uint8 * 32)()
+        t = np.ascontiguousarray(trace)
+        yield "trace_commit", L.ms_trace_commit(h, t.ctypes.data_as(u64p), C.c_size_t(N), C.c_size_t(3), C.c_size_t(6), root)
+        yield "interpolate", L.ms_interpolate(h)
+        for sc, idx in fibonacci_closures(field, N, omega):
+            yield "polys_lincomb", L.ms_polys_lincomb(h, (C.c_uint64 * len(sc))(*sc), (C.c_int * len(idx))(*idx), len(sc))
+        yield "lde_commit", L.ms_lde_commit(h, C.c_size_t(blowup), C.c_uint64(rng.nonzero(p)), C.c_size_t(6), root)
+        yield "mix", L.ms_mix(h, C.c_uint64(rng.field(p)))
+        out = (C.c_uint64 * (7 * e))()
+        yield "eval_ext", L.ms_eval_ext(h, (C.c_uint64 * e)(*[rng.field(p) for _ in range(e)]), 1, out)
+        yield "fri_begin", L.ms_fri_begin(h, C.c_size_t(blowup), C.c_size_t(rounds), root)
+        B = (C.c_uint64 * (2 * e))()
+        for _ in range(1, rounds):
+            yield "fri_deep", L.ms_fri_deep(h, (C.c_uint64 * e)(*[rng.field(p) for _ in range(e)]), B)
+            yield "fri_fold_commit", L.ms_fri_fold_commit(h, (C.c_uint64 * e)(*[rng.field(p) for _ in range(e)]), root)
+        yield "fri_query", L.ms_fri_query(h, (C.c_uint64 * 2)(3, 77), 2)
+        yield "ntt", L.ms_ntt(h, (C.c_uint64 * 64)(*range(64)), C.c_size_t(64), C.c_size_t(1), 0)
+        yield "merkle_commit", L.ms_merkle_commit(h, (C.c_uint64 * 16)(*range(16)), C.c_size_t(16), 1, C.c_size_t(2), C.c_size_t(2), None, C.c_size_t(0), None, root)
+
+    # ms_create itself under allocation failure: a negative code, no context
+    for k in range(6):
+        L.ms_emu_fail_alloc_after(k)
+        h = C.c_void_p()
+        rc = L.ms_create(C.byref(h), 0, field, 1)
+        L.ms_emu_fail_alloc_after(-1)
+        assert rc in (0, ms.ERR_NOMEM)
+        if rc == 0:
+            L.ms_destroy(h)
+        else:
+            assert not h.value
+    h = C.c_void_p()
+    assert L.ms_create(C.byref(h), 0, field, 1) == 0
+    assert all(rc == 0 for _, rc in stages(h))   # (the first proof also builds the NTT plans, which later proofs reuse)
+    n0 = L.ms_emu_alloc_count()
+    assert all(rc == 0 for _, rc in stages(h))
+    total = L.ms_emu_alloc_count() - n0
+    assert total > 50            # the job tables, plans and error texts do allocate: the guard has something to catch
+    hit = 0
+    for k in range(total + 3):
+        L.ms_emu_fail_alloc_after(k)
+        failed = None
+        for name, rc in stages(h):
+            if rc != 0:
+                failed = (name, rc)
+                break
+        L.ms_emu_fail_alloc_after(-1)
+        if failed is not None:
+            hit += 1
+            assert failed[1] in (ms.ERR_NOMEM, ms.ERR_HIP), (k, failed)
+            L.ms_last_error.restype = C.c_char_p
+            assert L.ms_last_error(h)            # readable, no allocation needed
+    assert hit == total, (hit, total)   # every single allocation of a proof, when it fails, surfaces as a negative status of the stage that made it
+    L.ms_destroy(h)
+    # after all that the library still proves: same bytes as the oracle
+    pc.case_prove(lambda f, fresh=False: ms.Context(f, lib_path=EMU), field, 4, 4, read_big=False)

@@ -429,10 +429,10 @@ def test_async_proof_readback_on_gpu(mk):
     assert ctx.L.ms_io_engine(ctx.h) == (0 if os.environ.get("MS_READBACK") == "hip" else 1), "the SDMA read-back did not bind: " + ctx.last_error()
 
 
-@pytest.mark.parametrize("mode", ["hip", "sdma", "sdma-all"])
+@pytest.mark.parametrize("mode", ["hip", "sdma-async", "sdma"])
 def test_readback_engines_deliver_the_same_bytes(monkeypatch, mode):
     """The three read-back paths of the boundary (MS_READBACK: the HIP runtime's copy, the SDMA engine for the asynchronous read-back, the SDMA engine for the
-    blocking one too) on a 2^18-row proof (16 MiB of FRI proof): same bytes in every mode, blocking and asynchronous, and ms_io_engine names the path taken."""
+    blocking one too: the default) on a 2^18-row proof (16 MiB of FRI proof): same bytes in every mode, blocking and asynchronous, and ms_io_engine names the path taken."""
     from mini_stark_amd.host import HostStark
     from mini_stark_amd.stark import fibonacci_air
     monkeypatch.setenv("MS_READBACK", "hip")
@@ -445,7 +445,7 @@ def test_readback_engines_deliver_the_same_bytes(monkeypatch, mode):
     ctx = ms.Context(0)
     hs = HostStark(ctx, 20, blowup, steps, tt.constrain_number())
     assert hs.prove(tt).fri_proof.blob == want                      # blocking read-back
-    assert ctx.L.ms_io_engine(ctx.h) == (1 if mode == "sdma-all" else 0)
+    assert ctx.L.ms_io_engine(ctx.h) == (1 if mode == "sdma" else 0)
     for _ in range(3):
         ctx.check(hs.prove_raw(tt, read_fri_proof="async"))
     assert hs.wait_proof() == 0

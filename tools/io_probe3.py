@@ -24,10 +24,11 @@ class G:
 
 
 # name, read-back on, read-back mode, MS_READBACK, upload on, MS_UPLOAD
-VARIANTS = [("resident", False, None, "sdma", False, "hip"), ("async_hip", True, "async", "hip", True, "hip"), ("async_sdma", True, "async", "sdma", True, "hip"),
-            ("blocking_hip", True, True, "hip", True, "hip"), ("blocking_sdma", True, True, "sdma-all", True, "hip"),
+VARIANTS = [("resident", False, None, "sdma", False, "hip"), ("async_hip", True, "async", "hip", True, "hip"), ("async_sdma", True, "async", "sdma-async", True, "hip"),
+            ("blocking_hip", True, True, "hip", True, "hip"), ("blocking_sdma", True, True, "sdma", True, "hip"),
             ("upload_only_hip", False, None, "sdma", True, "hip"), ("upload_only_sdma", False, None, "sdma", True, "sdma"),
-            ("readback_only_sdma", True, "async", "sdma", False, "hip"), ("async_sdma_upload_sdma", True, "async", "sdma", True, "sdma")]
+            ("readback_only_sdma", True, "async", "sdma", False, "hip"), ("async_sdma_upload_sdma", True, "async", "sdma", True, "sdma"),
+            ("blocking_sdma_upload_sdma", True, True, "sdma", True, "sdma")]
 if args.only:
     VARIANTS = [v for v in VARIANTS if v[0] in args.only.split(",")]
 dev = torch.device("cuda", 0)

@@ -2,7 +2,7 @@
 """Where a tile's time goes inside the cooperative NTT pass kernels (GPU).
 
 Builds a variant of the library with -DMS_NTT_TS (wave 0 of every workgroup stamps the shader clock at the phase boundaries of its first 16
-work items; csrc/ntt.hpp `MS_TS`), runs the device-resident six-column coset LDE once and prints, per kernel mode, the mean clocks of every
+work items; `MS_TS` of tools/ntt_instrumented.patch, applied to a copy of csrc/ for this build), runs the device-resident six-column coset LDE once and prints, per kernel mode, the mean clocks of every
 phase of a work item as wave 0 sees them:
 
   load   item start -> tile in LDS (global loads issued, waited for and written to LDS; behind the virtual pass: hand-over + expansion)
@@ -20,10 +20,23 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "_build", "libministark_ts.so")   # --out overrides
 
 
-def build(extra):
+def instrumented_tree():
+    """A copy of csrc/ with tools/ntt_instrumented.patch applied (the phase stamps MS_TS and the timing-only ablation branches MS_NTT_ABL_HOTLOAD / _NOSTORE live in the
+    patch, not in the product source: VERDICT r3 #7).  Returns the directory that holds include/ and csrc/."""
+    import shutil
+    top = os.path.join(ROOT, "tools", "_build", "instr")
+    shutil.rmtree(top, ignore_errors=True)
+    os.makedirs(os.path.join(top, "pkg"))
+    shutil.copytree(os.path.join(ROOT, "mini-stark_amd", "csrc"), os.path.join(top, "pkg", "csrc"))
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(top, "include"))
+    subprocess.check_call(["patch", "-s", "-p1", "-d", os.path.join(top, "pkg"), "-i", os.path.join(ROOT, "tools", "ntt_instrumented.patch")])
+    return top
+
+
+def build(extra, defines=("-DMS_NTT_TS",)):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    src = os.path.join(ROOT, "mini-stark_amd", "csrc", "ministark.cpp")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-DMS_NTT_TS"] + extra + ["-x", "hip", src, "-o", OUT]
+    src = os.path.join(instrumented_tree(), "pkg", "csrc", "ministark.cpp")   # (includes ../../include/ministark.h relative to itself)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed"] + list(defines) + extra + ["-x", "hip", src, "-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 
