@@ -122,9 +122,21 @@ def launch_ranks(args, argv):
     if args.mode == "replicas" and not args.no_shard_leg:
         sargv = ["--gpus", str(world), "--mode", "shard", "--log-rows", str(args.shard_log_rows), "--steps", str(args.shard_steps), "--warmup", "1", "--backend", args.backend,
                  "--field", str(args.field), "--blowup", str(args.blowup), "--no-cpu-baseline", "--no-extras"] + (["--emu"] if args.emu else [])
-        rc2, lines2, failed2 = _run_wave(sargv, world, timeout=args.shard_timeout)
+        # the sliced digest exchange (hashing overlapped with the all-to-all on a second stream) has never run on more than one GPU: try it first, and if that
+        # wave fails or disagrees with the unsharded proof, run the plain exchange in a fresh wave and say which one the numbers come from
+        rc2, lines2, failed2 = _run_wave(sargv, world, timeout=args.shard_timeout, extra_env={"MS_SHARD_SLICES": os.environ.get("MS_SHARD_SLICES", "4")})
         js2 = [l for l in lines2 if l.startswith("{")]
-        if rc2 == 0 and js2:
+        ok2 = rc2 == 0 and js2 and (json.loads(js2[-1])["exchange"].get("matches_unsharded") or {}).get("all", True)
+        if not ok2 and "MS_SHARD_SLICES" not in os.environ:
+            first_try = {"rc": rc2, "failed_rank": failed2, "matches_unsharded": (json.loads(js2[-1])["exchange"].get("matches_unsharded") if js2 else None)}
+            rc2, lines2, failed2 = _run_wave(sargv, world, timeout=args.shard_timeout, extra_env={"MS_SHARD_SLICES": "1"})
+            js2 = [l for l in lines2 if l.startswith("{")]
+            if rc2 == 0 and js2:
+                out["sharded"] = json.loads(js2[-1])["exchange"]
+                out["sharded"]["sliced_exchange_first_try"] = first_try
+        if "sharded" in out:
+            pass
+        elif rc2 == 0 and js2:
             out["sharded"] = json.loads(js2[-1])["exchange"]
         elif rc2 == 124:
             out["sharded"] = {"error": f"the sharded leg did not finish within {args.shard_timeout:.0f} s; headline unaffected"}
@@ -197,7 +209,10 @@ class Lanes:
 
     def timed(self, grp, steps, warmup):
         if self.n > 1:
-            self._prove_n(0, 1)   # untimed: every kernel's first launch (HIP loads code objects lazily) happens on ONE thread before the lanes start
+            # untimed: every kernel's first launch happens on ONE thread before the lanes start.  HIP loads a module's code object and resolves a kernel on its first
+            # launch under a runtime lock; eight threads doing that at once serialise there and the one-off cost would land in the lanes' warm-up (or, with --warmup 0,
+            # timed) proofs.  A timing measure, not a correctness workaround (profiles/r04_sigsegv_analysis.md)
+            self._prove_n(0, 1)
         self.run(warmup)
         grp.barrier()
         t0 = time.perf_counter()
@@ -230,6 +245,7 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
     else:
         xchg = ShardExchange(grp, ctx, cap, staged=not args.emu, buffer_device=dev)
         how = "gloo rehearsal through the exchange callback (payloads staged through host memory)"
+    ctx.shard_proof_on_root(True)    # Stark::prove returns ONE proof: the ranks' slices of the FRI proof are gathered to rank 0 (not all-gathered)
     tt = fibonacci_air(ctx, N - 1)   # every rank holds the same trace
     cfg = StarkConfig(ctx, 20, args.blowup, N - 1, tt.constrain_number())
     hs = HostStark(ctx, 20, args.blowup, N - 1, tt.constrain_number())
@@ -252,7 +268,7 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
     nbytes = xchg.bytes
     dist_rounds = sum(1 for i in range(cfg.rounds) if ctx.L.ms_shard_round_is_distributed(ctx.h, C.c_int(i)) == 1)
     # one more (untimed) proof with every launch bracketed by HIP events: kernel time of this rank's PART of the proof vs kernel time REPLICATED on every rank
-    buf = C.create_string_buffer(1 << 14)
+    buf = C.create_string_buffer(1 << 15)
     ctx.check(ctx.L.ms_profile_begin(ctx.h))
     prove(1)
     ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
@@ -279,7 +295,8 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
            "collective_calls_per_rank": {n: calls[i] for i, n in enumerate(["all_to_all", "all_gather", "all_reduce_min", "all_reduce_sum"])},
            "collective_calls_per_rank_per_proof": {n: calls[i] / max(1, steps + warmup) for i, n in enumerate(["all_to_all", "all_gather", "all_reduce_min", "all_reduce_sum"])},
            "bytes_sent_per_rank": nbytes, "proofs": steps + warmup,
-           "distributed_rounds": dist_rounds, "rounds": cfg.rounds,
+           "distributed_rounds": dist_rounds, "rounds": cfg.rounds, "fri_proof_assembled_on": "rank 0 only (ms_shard_proof_on_root)",
+           "digest_exchange_slices": int(os.environ.get("MS_SHARD_SLICES", "1" if args.backend == "nccl" else "4")),
            "partitioned_ms_estimate": shard_prof.get("partitioned_ms"), "replicated_ms_estimate": shard_prof.get("replicated_ms"),
            "replicated_ms_note": "rank 0, one extra proof with per-launch HIP events (they add launch overhead): kernel time of launches that work on this rank's 1/world part of the proof "
                                  "(partitioned) and of launches every rank repeats (replicated: INTT, constraint polynomials, mix, tree tops, commitments below MS_SHARD_MIN_LEAVES); "
@@ -308,7 +325,7 @@ def profile_is_current(round_tag):
 
 def load_sq_profile():
     """VALU wave-instructions per thread per (kernel, grid) from this round's rocprofv3 SQ-counter pass (tools/process_profiles.py)."""
-    for name in ("r03_sq_counters_top_kernels.csv", "r02_sq_counters_top_kernels.csv", "r01_sq_counters_top_kernels.csv"):
+    for name in ("r04_sq_counters_top_kernels.csv", "r03_sq_counters_top_kernels.csv", "r02_sq_counters_top_kernels.csv", "r01_sq_counters_top_kernels.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             rows = list(csv.DictReader(open(path)))
@@ -442,7 +459,7 @@ def main():
             lanes = Lanes(args.field, args.log_rows, args.blowup, 1, local_rank, dev)
         ctx = lanes.ctxs[0]
         # ---- roofline leg: per-kernel HIP events on the launching stream, one extra (untimed) proof
-        buf = C.create_string_buffer(1 << 14)
+        buf = C.create_string_buffer(1 << 15)
         ctx.check(ctx.L.ms_profile_begin(ctx.h))
         lanes._prove_n(0, 1)
         ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
@@ -454,7 +471,7 @@ def main():
         avg_ms = k["ms"] / max(1, k["launches"])
         achieved = (k["alg_bytes"] / max(1, k["launches"])) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src, pmc_variants = None, None, {}
-        for name in ("r03_pmc_ntt_pass.json", "r02_pmc_ntt_pass.json", "pmc_ntt_pass.json"):
+        for name in ("r04_pmc_ntt_pass.json", "r03_pmc_ntt_pass.json", "r02_pmc_ntt_pass.json", "pmc_ntt_pass.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -472,7 +489,7 @@ def main():
             per_variant[vn] = {"launches_per_proof": v["launches"], "avg_launch_ms": a_ms, "alg_GBps": (v["alg_bytes"] / max(1, v["launches"])) / (a_ms * 1e-3) / 1e9 if a_ms else 0.0,
                                "traffic_bytes_per_launch": tb, "frac_of_hbm_peak_on_traffic": (tb / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb and a_ms else None}
         allp = prof["ntt_pass"]
-        out["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        out["roofline"] = {"kernel": kname, "bound": "hbm", "limited_by": "valu_issue+access_pattern", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied; a constant, not measured in this run)") if traffic_src else None,
                            "traffic_profile_taken_from_this_kernel_source": profile_is_current(traffic_src.split("/")[1][:3]) if traffic_src else None,
                            "frac_on_traffic": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,

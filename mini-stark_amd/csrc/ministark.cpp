@@ -345,12 +345,12 @@ template <class F> struct Ctx : CtxBase {
     static const char* names[K_COUNT] = {"ntt_pass", "scale_pow", "leaf_hash", "inner_hash", "transpose_in", "io_copy", "lincomb", "mix", "eval", "eval_reduce",
                                          "fold", "suffix_horner", "degree", "find_first", "merkle_path", "query_points"};
     msrt::sync(stream);
-    double ms[K_COUNT] = {0}, by[K_COUNT] = {0}, ms_part = 0, ms_repl = 0; unsigned long long cnt[K_COUNT] = {0};
+    double ms[K_COUNT] = {0}, by[K_COUNT] = {0}, ms_part = 0, ms_repl = 0, repl_by[K_COUNT] = {0}; unsigned long long cnt[K_COUNT] = {0};
     std::map<int, double> sub_ms, sub_by; std::map<int, unsigned long long> sub_cnt;
     for (auto& r : prof_recs) {
       float t = 0.f; msrt::event_elapsed_ms(&t, r.a, r.b);
       ms[r.kid] += t; by[r.kid] += r.bytes; cnt[r.kid]++;
-      if (r.part) ms_part += t; else ms_repl += t;
+      if (r.part) ms_part += t; else { ms_repl += t; repl_by[r.kid] += t; }
       if (r.kid == K_NTT_PASS) { sub_ms[r.sub] += t; sub_by[r.sub] += r.bytes; sub_cnt[r.sub]++; }
       msrt::event_destroy(r.a); msrt::event_destroy(r.b);
     }
@@ -371,7 +371,10 @@ template <class F> struct Ctx : CtxBase {
       j += buf; first = false;
     }
     j += "}";
-    { char buf[200]; snprintf(buf, sizeof buf, ", \"shard\": {\"world\": %d, \"partitioned_ms\": %.6f, \"replicated_ms\": %.6f}}", sh_world, ms_part, ms_repl); j += buf; }
+    { char buf[200]; snprintf(buf, sizeof buf, ", \"shard\": {\"world\": %d, \"partitioned_ms\": %.6f, \"replicated_ms\": %.6f, \"replicated_by_kernel\": {", sh_world, ms_part, ms_repl); j += buf;
+      bool first_k = true;
+      for (int k = 0; k < K_COUNT; k++) if (repl_by[k] > 0) { snprintf(buf, sizeof buf, "%s\"%s\": %.4f", first_k ? "" : ", ", names[k], repl_by[k]); j += buf; first_k = false; }
+      j += "}}}"; }
     if (out && cap) { size_t n = j.size() < cap - 1 ? j.size() : cap - 1; memcpy(out, j.data(), n); out[n] = 0; }
     return 0;
   }

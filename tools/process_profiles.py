@@ -3,11 +3,15 @@
 import csv, glob, json, collections, os, shutil, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 O = f"gpurun_out/prof_{R}"
-one = lambda pat: max(glob.glob(pat), key=os.path.getmtime)   # gpurun merges every call's output into the same tree: take the newest
-try:
-    shutil.copy(one(O + "/stats/*/*kernel_stats.csv"), f"profiles/{R}_kernel_stats.csv")
-except ValueError:
-    print("no 8-lane kernel-stats pass in this run (rocprofv3 crashed): profiles/%s_kernel_stats.csv left as it is" % R)
+# no silent reuse of an older run's files.  tools/profile_round.sh wipes its output directory, stamps the start, and records rc 0 only if EVERY pass succeeded;
+# the local gpurun_out/ is a merge of many calls, so every file taken here must be newer than that start stamp.
+done = json.load(open(O + "/passes_done.json"))
+assert done["rc"] == 0, f"tools/profile_round.sh {R} did not complete (rc {done['rc']}): no summaries are produced from a partial run"
+T0 = int(open(O + "/started_at").read())
+def one(pat):
+    fresh = [f for f in glob.glob(pat) if os.path.getmtime(f) >= T0 - 5]
+    assert fresh, f"no file of THIS profile run matches {pat} (older ones are not taken)"
+    return max(fresh, key=os.path.getmtime)
 shutil.copy(one(O + "/stats1/*/*kernel_stats.csv"), f"profiles/{R}_kernel_stats_inflight1.csv")
 bench = [json.loads(l) for l in open(O + "/bench_default.json") if l.startswith("{")][-1]
 KN = bench["roofline"]["kernel"].replace("msntt::", "")
@@ -146,5 +150,6 @@ import hashlib
 hsh = hashlib.sha256()
 for fn in ("ntt.hpp", "field.hpp", "merkle.hpp", "poly.hpp"):
     hsh.update(open(os.path.join("mini-stark_amd", "csrc", fn), "rb").read())
-json.dump({"round": R, "kernel_source_sha256": hsh.hexdigest(), "files": ["ntt.hpp", "field.hpp", "merkle.hpp", "poly.hpp"]}, open(f"profiles/{R}_profile_meta.json", "w"))
+json.dump({"round": R, "kernel_source_sha256": hsh.hexdigest(), "files": ["ntt.hpp", "field.hpp", "merkle.hpp", "poly.hpp"], "profile_run_started_at": T0, "profile_run_rc": done["rc"],
+           "every_pass_succeeded": True}, open(f"profiles/{R}_profile_meta.json", "w"))
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step")}), bench["roofline"])

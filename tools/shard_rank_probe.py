@@ -66,14 +66,14 @@ def one(world, dist):
     ts = []
     for _ in range(args.reps):
         t0 = time.perf_counter(); prove(); ts.append((time.perf_counter() - t0) * 1e3)
-    buf = C.create_string_buffer(1 << 14)
+    buf = C.create_string_buffer(1 << 15)
     ctx.check(ctx.L.ms_profile_begin(ctx.h)); prove(); ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
     prof = json.loads(buf.value.decode())
     sh = prof.pop("shard", {})
     prof.pop("ntt_pass_variants", None)
     res = {"world": world, "shard_dist": dist, "log_rows": args.log_rows, "ms_wall_min": round(min(ts), 3), "ms_wall_all": [round(t, 3) for t in ts],
            "kernel_ms_total": round(sum(v["ms"] for v in prof.values()), 3), "partitioned_ms": sh.get("partitioned_ms"), "replicated_ms": sh.get("replicated_ms"),
-           "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]},
+           "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}, "replicated_by_kernel": sh.get("replicated_by_kernel"),
            "launches": sum(v["launches"] for v in prof.values()), "collective_calls": stub.calls if stub else {}}
     if stub:
         ctx.set_shard(0, 1, 0, 0, 0, None)
