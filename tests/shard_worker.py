@@ -31,6 +31,15 @@ else:
     ctx = ms.Context(field, lib_path=os.environ.get("MS_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "libministark_emu.so"))  # MS_EMU_LIB: sanitizer builds
     xchg = ShardExchange(grp, ctx, cap)
 trace = fibonacci_trace_fast(field, N)
+if "low-degree" in modes:   # trace columns of degree N/2 + 2: the validity polynomial fills only half of round 0's coefficient ranges - ranks above world / 2 hold (almost) nothing, a middle rank holds the ragged top
+    import numpy as np
+    from common import MODULUS
+    cols = []
+    for c in range(3):
+        coef = np.zeros(N, dtype=np.uint64)
+        coef[: N // 2 + 3] = pc.rand_field(field, (N // 2 + 3,), seed=40 + c)
+        cols.append(orc.ntt(field, coef))
+    trace = np.ascontiguousarray(np.stack(cols, axis=1))
 if log_n >= 16:  # full-size comparisons: OpenMP over the oracle's independent loops (every rank runs its own oracle)
     orc.set_threads(max(1, min(8, len(os.sched_getaffinity(0)) // grp.world)))
 root_only = "root-only" in modes        # ms_shard_proof_on_root: only rank 0 ends up with the FRI proof

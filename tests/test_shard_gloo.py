@@ -81,3 +81,11 @@ def test_sharded_multilevel_scans_and_chunked_proof_gather(world, field, log_n, 
     proof slices that cross the exchange buffer in several pieces (MS_SHARD_GATHER_CHUNK forces small pieces), all-gathered and gathered to rank 0."""
     res = run_world(world, field, log_n, 8, 16, 29300 + world * 10 + field * 3 + log_n + (5 if mode else 0), env=env, mode=mode)
     assert res["world"] == world and res["dist_rounds"] >= 8
+
+
+@pytest.mark.parametrize("world,field,log_n", [(4, 0, 9), (8, 0, 11), (8, 1, 10), (2, 1, 8)])
+def test_sharded_proof_with_half_empty_coefficient_ranges(world, field, log_n):
+    """Trace polynomials of degree N/2 + 2: FRI's round-0 domain is sized for N coefficients but the polynomial has N/2 + 3, so the upper ranks' coefficient ranges are
+    empty and one rank holds the ragged top - empty scan jobs, zero aggregates in the carry chain, slices of length zero in the proof gather."""
+    res = run_world(world, field, log_n, 8, 16, 29200 + world * 10 + field * 3 + log_n, mode="low-degree")
+    assert res["world"] == world and res["dist_rounds"] >= 2
