@@ -43,7 +43,8 @@ N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32, 2.4 GHz max clock (same g
 
 def default_inflight(log_rows):
     # 8 fills the 4 hardware queues twice over at the benchmark size; larger proofs need the HBM (25 GiB each at 2^24 rows)
-    return 8 if log_rows <= 20 else (4 if log_rows == 21 else (3 if log_rows == 22 else 2))
+    # (2^24 rows: 25 GiB resident per proof; same-box A/B r04: 2 in flight 16.4-16.5 proofs/s, 3: 17.0-17.3, 4: 17.3-17.5 - profiles/r04_ab_2p24_inflight.log)
+    return 8 if log_rows <= 20 else (6 if log_rows == 21 else 4)
 
 
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "libministark_emu.so")

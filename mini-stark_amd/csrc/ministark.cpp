@@ -877,6 +877,24 @@ template <class F> struct Ctx : CtxBase {
   int npolys = 0; size_t polys_cap = 0;
   struct Lin { std::vector<u64> s; std::vector<int> idx; };   // provenance of polynomial i: a linear combination of earlier ones (empty: none)
   std::vector<Lin> poly_lin;
+  // r04, linear provenance carried through the coefficient domain: a polynomial ms_polys_lincomb defined is not computed when it is defined.  Its LDE column is the
+  // combination of the computed LDE columns (as before), the mix is ONE linear combination of the polynomials without provenance with the scalars
+  // sum_i r^i * (coefficient of that polynomial in f_i), and its DEEP-ALI value is the same combination of the opened values - exact field arithmetic, so every
+  // output is bit-identical.  The coefficient vector is materialised on demand only (ms_poly_read, MS_LDE_LINEAR=0).  MS_LAZY_LINCOMB=0: computed at definition (r03).
+  std::vector<char> poly_mat; int lazy_lin = 1;
+  void expand(int i, T scale, std::map<int, T>& acc) const {   // f_i as a combination of the polynomials without provenance
+    const Lin& li = poly_lin[i];
+    if (li.idx.empty()) { auto it = acc.find(i); if (it == acc.end()) acc[i] = scale; else it->second = F::add(it->second, scale); return; }
+    for (size_t t = 0; t < li.idx.size(); t++) expand(li.idx[t], F::mul(scale, F::from_u64(li.s[t] % F::P)), acc);
+  }
+  int materialize(int i) {
+    if (poly_mat[i]) return 0;
+    const Lin& li = poly_lin[i];
+    for (int ix : li.idx) RQ(materialize(ix));
+    RQ(lincomb_into(d_polys.as<T>(), N, N, li.s.data(), li.idx.data(), (int)li.idx.size(), i, d_polys.as<T>() + (size_t)i * N));
+    poly_mat[i] = 1;
+    return 0;
+  }
   bool have_trace = false, have_polys = false, have_lde = false, have_validity = false;
   DevBuf d_trace, d_polys, d_coef, d_lde, d_trace_nodes, d_lde_nodes, d_io, d_partials, d_small;
   TreeShape trace_ts, lde_ts;
@@ -936,6 +954,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_MALL_MIB")) { int v = atoi(e); if (v >= 1) ntt_mall_mib = v; }
     if (const char* e = getenv("MS_NTT_V2_MIN")) { int v = atoi(e); if (v >= 12 && v <= 32) ntt_v2_min = v; }
     if (const char* e = getenv("MS_LDE_LINEAR")) lde_linear = atoi(e);
+    if (const char* e = getenv("MS_LAZY_LINCOMB")) lazy_lin = atoi(e);
     if (const char* e = getenv("MS_LDE_MULTI")) lde_multi = atoi(e);
     if (const char* e = getenv("MS_LDE_VIRTUAL")) lde_virtual = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
@@ -1057,6 +1076,7 @@ template <class F> struct Ctx : CtxBase {
     if (!have_trace) return fail(MS_ERR_STATE, "interpolate before trace_commit");
     RQ(ntt_run(ctz64(N), true, d_polys.as<T>(), N, N, d_polys.as<T>(), N, w));
     poly_lin.assign(w, Lin());   // (first: if this allocation fails the session keeps no half-set state)
+    poly_mat.assign(w, 1);
     npolys = (int)w; have_polys = true; have_lde = have_validity = false;
     return MS_OK;
   }
@@ -1065,7 +1085,8 @@ template <class F> struct Ctx : CtxBase {
     if (!s || !idx || k < 1) return fail(MS_ERR_ARG, "bad lincomb arguments");
     for (int t = 0; t < k; t++) if (idx[t] < 0 || idx[t] >= npolys || s[t] >= F::P) return fail(MS_ERR_ARG, "lincomb index/scalar out of range");
     RQ(ensure_polys(npolys + 2));
-    RQ(lincomb_into(d_polys.as<T>(), N, N, s, idx, k, npolys, d_polys.as<T>() + (size_t)npolys * N));
+    if (!lazy_lin) RQ(lincomb_into(d_polys.as<T>(), N, N, s, idx, k, npolys, d_polys.as<T>() + (size_t)npolys * N));
+    poly_mat.push_back(lazy_lin ? 0 : 1);
     { Lin l; l.s.assign(s, s + k); l.idx.assign(idx, idx + k); poly_lin.push_back(l); }
     npolys++; have_lde = have_validity = false;
     return MS_OK;
@@ -1078,6 +1099,7 @@ template <class F> struct Ctx : CtxBase {
     T* dst = d_polys.as<T>() + (size_t)npolys * N;
     CK(msrt::memset_dev(dst, 0, N * sizeof(T), stream));
     if (n) { RQ(upload_narrow(coeffs, n, dst)); CK(msrt::sync(stream)); }   // the caller's buffer is only read during the call (include/ministark.h)
+    poly_mat.push_back(1);
     poly_lin.push_back(Lin());
     npolys++; have_lde = have_validity = false;
     return MS_OK;
@@ -1085,6 +1107,7 @@ template <class F> struct Ctx : CtxBase {
   int polys_count() const override { return npolys; }
   int poly_read(int i, u64* out) override {
     if (!have_polys || i < 0 || i >= npolys || !out) return fail(MS_ERR_ARG, "poly_read");
+    RQ(materialize(i));
     return download_widen(d_polys.as<T>() + (size_t)i * N, N, 0, 1, out);
   }
 
@@ -1154,6 +1177,7 @@ template <class F> struct Ctx : CtxBase {
     const size_t c = (size_t)npolys;
     const size_t L_ = N * blowup_;
     if (d_coef.ensure(c * N * sizeof(T)) || d_lde.ensure(c * L_ * sizeof(T))) return fail(MS_ERR_NOMEM, "lde");
+    if (!lde_linear) for (size_t i = 0; i < c; i++) RQ(materialize((int)i));
     const T sh = F::from_u64(shift), sh_step = f_pow<F>(sh, msntt::ScalePowKernel<F>::THREADS);
     const int per_block = msntt::ScalePowKernel<F>::THREADS * msntt::ScalePowKernel<F>::ITEMS;
     for (size_t i = 0; i < c;) {  // maximal runs of polynomials that need a transform
@@ -1230,6 +1254,7 @@ template <class F> struct Ctx : CtxBase {
   int lde_compute_sharded(size_t blowup_, u64 shift) {
     const size_t c = (size_t)npolys, L_ = N * blowup_, m = L_ / (size_t)sh_world;
     if (d_lde.ensure(c * m * sizeof(T))) return fail(MS_ERR_NOMEM, "lde");
+    if (!lde_linear) for (size_t i = 0; i < c; i++) RQ(materialize((int)i));
     PartScope part(this);
     for (size_t i = 0; i < c;) {
       if (lde_linear && !poly_lin[i].idx.empty()) { i++; continue; }
@@ -1305,8 +1330,21 @@ template <class F> struct Ctx : CtxBase {
     if (!have_polys) return fail(MS_ERR_STATE, "mix before interpolate");
     if (r >= F::P) return fail(MS_ERR_ARG, "r not canonical");
     RQ(ensure_polys(npolys + 1));
+    bool any_lazy = false;
+    for (int i = 0; i < npolys; i++) any_lazy = any_lazy || !poly_mat[i];
+    if (any_lazy) {   // sum_i r^i f_i as ONE combination of the polynomials without provenance (the lazily defined f_i are never formed)
+      std::map<int, T> acc;
+      T rp = F::from_u64(1);
+      for (int i = 0; i < npolys; i++) { expand(i, rp, acc); rp = F::mul(rp, F::from_u64(r)); }
+      std::vector<u64> sc; std::vector<int> ix;
+      for (auto& kv : acc) if (kv.second != 0) { sc.push_back(F::to_u64(kv.second)); ix.push_back(kv.first); }
+      T* dst = d_polys.as<T>() + (size_t)npolys * N;
+      if (sc.empty()) CK(msrt::memset_dev(dst, 0, N * sizeof(T), stream));
+      else RQ(lincomb_into(d_polys.as<T>(), N, N, sc.data(), ix.data(), (int)sc.size(), npolys, dst));
+    } else {
     typename mspoly::MixKernel<F>::Params p{d_polys.as<T>(), N, N, npolys, F::from_u64(r), d_polys.as<T>() + (size_t)npolys * N};
     CK(run<mspoly::MixKernel<F>>(K_MIX, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
+    }
     have_validity = true; validity_len = N; nrounds_done = 0;
     return MS_OK;
   }
@@ -1417,28 +1455,51 @@ template <class F> struct Ctx : CtxBase {
   // DEEP-ALI evaluations by coefficient range (r04): rank k evaluates the coefficients [k*Sx, (k+1)*Sx) of every polynomial at every point, ONE all-gather of the partial
   // sums, and every rank combines them with z^Sx
   bool dist_eval() const { return sh_world > 1 && shard_dist && N >= shard_min_leaves && N >= (size_t)sh_world * 2; }
+  // the polynomials the DEEP-ALI kernels evaluate: those whose coefficients exist, then the validity polynomial (index npolys); the lazily defined ones get their
+  // values on the host as the combination their provenance names (eval_finish)
+  std::vector<int> eval_set() const { std::vector<int> ev; for (int i = 0; i < npolys; i++) if (poly_mat[i]) ev.push_back(i); ev.push_back(npolys); return ev; }
+  // page-locked results [q][ev.size()][E] -> out [q][npolys + 1][E] (u64)
+  int eval_finish(int q, const std::vector<int>& ev, u64* out) {
+    const size_t nev = ev.size(), np = (size_t)npolys + 1;
+    const T* h = reinterpret_cast<const T*>(pinned);
+    std::vector<int> slot(np, -1);
+    for (size_t k = 0; k < nev; k++) slot[ev[k]] = (int)k;
+    std::vector<std::map<int, T>> exp_(np);
+    for (int i = 0; i < npolys; i++) if (slot[i] < 0) expand(i, F::from_u64(1), exp_[i]);
+    for (int t = 0; t < q; t++) {
+      const T* ht = h + (size_t)t * nev * E;
+      for (size_t i = 0; i < np; i++) {
+        u64* o = out + ((size_t)t * np + i) * E;
+        if (slot[i] >= 0) { for (int l = 0; l < E; l++) o[l] = F::to_u64(ht[(size_t)slot[i] * E + l]); continue; }
+        XE acc = e_zero<F, E>();
+        for (auto& kv : exp_[i]) { XE v; for (int l = 0; l < E; l++) v.c[l] = ht[(size_t)slot[kv.first] * E + l]; acc = e_add<F, E>(acc, e_mul_base<F, E>(v, kv.second)); }
+        for (int l = 0; l < E; l++) o[l] = F::to_u64(acc.c[l]);
+      }
+    }
+    return MS_OK;
+  }
   int eval_ext_sharded(const u64* z, int q, u64* out) {
-    const int np = npolys + 1;
-    const size_t tot = (size_t)q * np * E, W = (size_t)sh_world;
+    const std::vector<int> ev = eval_set();
+    const int nev = (int)ev.size();
+    const size_t tot = (size_t)q * nev * E, W = (size_t)sh_world;
     const size_t maxlen = validity_len > N ? validity_len : N, Sx = maxlen / W, lo = (size_t)sh_rank * Sx;
     if (tot * sizeof(T) > pinned_cap) return fail(MS_ERR_ARG, "too many evaluation points");
     if (tot * sizeof(T) * W > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small for the DEEP-ALI partial sums");
     std::vector<XE> zs((size_t)q);
     for (int t = 0; t < q; t++) {
       if (!load_ext(z + (size_t)t * E, &zs[t])) return fail(MS_ERR_ARG, "query point not canonical");
-      for (int i0 = 0; i0 < np; i0 += mspoly::MAX_POLYS) {
-        const int nb = (np - i0 < mspoly::MAX_POLYS) ? np - i0 : mspoly::MAX_POLYS;
+      for (int i0 = 0; i0 < nev; i0 += mspoly::MAX_POLYS) {
+        const int nb = (nev - i0 < mspoly::MAX_POLYS) ? nev - i0 : mspoly::MAX_POLYS;
         size_t off[mspoly::MAX_POLYS], cnt[mspoly::MAX_POLYS];
-        for (int i = 0; i < nb; i++) { const size_t len = (i0 + i == npolys) ? validity_len : N; off[i] = lo; cnt[i] = len <= lo ? 0 : (len - lo < Sx ? len - lo : Sx); }
-        { PartScope part(this); RQ((eval_views<1>(d_polys.as<T>() + (size_t)i0 * N, N, 0, 1, off, cnt, nb, zs[t], reinterpret_cast<T*>(xs) + ((size_t)t * np + i0) * E))); }
+        for (int i = 0; i < nb; i++) { const int pi = ev[i0 + i]; const size_t len = (pi == npolys) ? validity_len : N; off[i] = (size_t)pi * N + lo; cnt[i] = len <= lo ? 0 : (len - lo < Sx ? len - lo : Sx); }
+        { PartScope part(this); RQ((eval_views<1>(d_polys.as<T>(), 0, 0, 1, off, cnt, nb, zs[t], reinterpret_cast<T*>(xs) + ((size_t)t * nev + i0) * E))); }
       }
     }
     if (tot) {
       RQ(exchange(MS_XCHG_ALL_GATHER, tot * sizeof(T)));
-      for (int t = 0; t < q; t++) RQ(shard_combine_launch((size_t)t * np * E, tot, (u32)np, e_pow<F, E>(zs[t], (u64)Sx), reinterpret_cast<T*>(pinned) + (size_t)t * np * E));
+      for (int t = 0; t < q; t++) RQ(shard_combine_launch((size_t)t * nev * E, tot, (u32)nev, e_pow<F, E>(zs[t], (u64)Sx), reinterpret_cast<T*>(pinned) + (size_t)t * nev * E));
       CK(msrt::sync(stream));
-      const T* h = reinterpret_cast<const T*>(pinned);
-      for (size_t i = 0; i < tot; i++) out[i] = F::to_u64(h[i]);
+      RQ(eval_finish(q, ev, out));
     }
     return MS_OK;
   }
@@ -1448,24 +1509,24 @@ template <class F> struct Ctx : CtxBase {
     if (!have_validity) return fail(MS_ERR_STATE, "eval_ext before mix");
     if (!z || !out || q < 0) return fail(MS_ERR_ARG, "eval_ext");
     if (dist_eval()) return eval_ext_sharded(z, q, out);
-    const int np = npolys + 1;
-    const size_t tot = (size_t)q * np * E;
+    const std::vector<int> ev = eval_set();
+    const int nev = (int)ev.size();
+    const size_t tot = (size_t)q * nev * E;
     if (d_small.ensure(tot * sizeof(T) + 4096)) return fail(MS_ERR_NOMEM, "small");
     if (tot * sizeof(T) > pinned_cap) return fail(MS_ERR_ARG, "too many evaluation points");
     for (int t = 0; t < q; t++) {
       XE zz;
       if (!load_ext(z + (size_t)t * E, &zz)) return fail(MS_ERR_ARG, "query point not canonical");
-      for (int i0 = 0; i0 < np; i0 += mspoly::MAX_POLYS) {
-        const int nb = (np - i0 < mspoly::MAX_POLYS) ? np - i0 : mspoly::MAX_POLYS;
+      for (int i0 = 0; i0 < nev; i0 += mspoly::MAX_POLYS) {
+        const int nb = (nev - i0 < mspoly::MAX_POLYS) ? nev - i0 : mspoly::MAX_POLYS;
         size_t off[mspoly::MAX_POLYS], cnt[mspoly::MAX_POLYS];
-        for (int i = 0; i < nb; i++) { off[i] = 0; cnt[i] = (i0 + i == npolys) ? validity_len : N; }   // the validity polynomial has 2N coefficients after ms_mix_cubic
-        RQ((eval_views<1>(d_polys.as<T>() + (size_t)i0 * N, N, 0, 1, off, cnt, nb, zz, reinterpret_cast<T*>(pinned) + ((size_t)t * np + i0) * E)));   // results land in page-locked host memory
+        for (int i = 0; i < nb; i++) { const int pi = ev[i0 + i]; off[i] = (size_t)pi * N; cnt[i] = (pi == npolys) ? validity_len : N; }   // the validity polynomial has 2N coefficients after ms_mix_cubic
+        RQ((eval_views<1>(d_polys.as<T>(), 0, 0, 1, off, cnt, nb, zz, reinterpret_cast<T*>(pinned) + ((size_t)t * nev + i0) * E)));   // results land in page-locked host memory
       }
     }
     if (tot) {
       CK(msrt::sync(stream));
-      const T* h = reinterpret_cast<const T*>(pinned);
-      for (size_t i = 0; i < tot; i++) out[i] = F::to_u64(h[i]);
+      RQ(eval_finish(q, ev, out));
     }
     return MS_OK;
   }
