@@ -213,9 +213,13 @@ struct Rccl {
 namespace msrt {
 inline int Rccl::load() {
   if (lib) return 0;
-  const char* names[] = {getenv("MS_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  const char* names[] = {getenv("MS_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
   void* h = nullptr;
-  for (const char* n : names) { if (n && *n) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; } }
+  if (const char* e = getenv("MS_RCCL_LIB")) { if (*e) h = dlopen(e, RTLD_NOW | RTLD_LOCAL); }
+  // the RCCL already mapped into the process first (PyTorch's, built against the HIP runtime the process runs on): a second copy from another ROCm release would work
+  // on a runtime it was not built for
+  if (!h) for (const char* n : names) { if (n && *n) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; } }
+  if (!h) for (const char* n : names) { if (n && *n) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; } }
   if (!h) return 1;
   auto sym = [&](const char* n) { return dlsym(h, n); };
   get_unique_id = (GetUniqueIdFn)sym("ncclGetUniqueId");
