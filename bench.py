@@ -202,11 +202,21 @@ class Lanes:
         if self.n == 1:
             self._prove_n(0, n)
             return
-        th = [threading.Thread(target=self._prove_n, args=(i, n)) for i in range(self.n)]
+        errs = [None] * self.n
+
+        def lane(i):
+            try:
+                self._prove_n(i, n)
+            except BaseException as e:  # noqa: BLE001 - re-raised below: a lane that died (e.g. MS_ERR_NOMEM with too many proofs in flight) must fail the run, not shorten it
+                errs[i] = e
+        th = [threading.Thread(target=lane, args=(i,)) for i in range(self.n)]
         for t in th:
             t.start()
         for t in th:
             t.join()
+        for i, e in enumerate(errs):
+            if e is not None:
+                raise RuntimeError(f"lane {i} of {self.n} failed: {e}") from e
 
     def timed(self, grp, steps, warmup):
         if self.n > 1:

@@ -2196,9 +2196,9 @@ template <class F> struct Ctx : CtxBase {
   bool sdma_ready() {
     if (!readback_sdma) return false;
     if (sdma_state == 0) {
-      sdma_state = 2;
       msrt::Sdma& S = msrt::Sdma::get();
-      if (!S.bind_device(device, &sdma_gpu) && !S.signal_create(&sdma_sig) && !S.signal_create(&sdma_up_sig)) sdma_state = 1;
+      if (!S.bind_device(device, &sdma_gpu)) sdma_state = (!S.signal_create(&sdma_sig) && !S.signal_create(&sdma_up_sig)) ? 1 : 2;
+      else if (S.unavailable()) sdma_state = 2;   // no HSA runtime to bind: this context stays on the HIP runtime's copies.  (Engines merely busy: asked again at the next copy.)
     }
     return sdma_state == 1;
   }

@@ -82,6 +82,7 @@ struct Sdma {
   unsigned h2d_engine(int) { return 0; }
   int wait(Signal, double) { return 1; }
   unsigned d2h_engine(int) { return 0; }
+  bool unavailable() const { return true; }
 };
 }  // namespace msrt
 // ---- cooperative kernels (K::run with workgroup barriers INSIDE the function, per-thread state alive across them): every thread of a
@@ -328,7 +329,7 @@ struct Sdma {
           uint32_t m = (pref & avail) ? (pref & avail) : (avail ? avail : pref);
           g.h2d_engine = m ? (m & (~m + 1)) : 0;
         }
-        if (!g.d2h_engine) dev_gpu[hip_device] = -1;
+        if (!g.d2h_engine) dev_gpu[hip_device] = -2;   // no engine reported free right now (all busy): not cached - the next caller asks again
       }
     }
     if (dev_gpu[hip_device] < 0) return 1;
@@ -336,7 +337,19 @@ struct Sdma {
     return 0;
   }
   unsigned d2h_engine(int gpu_index) { return gpus[gpu_index].d2h_engine; }
-  unsigned h2d_engine(int gpu_index) { return gpus[gpu_index].h2d_engine; }
+  bool unavailable() const { return state == 2; }   // the HSA runtime could not be bound at all (as opposed to: no engine free at this moment)
+  unsigned h2d_engine(int gpu_index) {
+    Gpu& g = gpus[gpu_index];
+    if (!g.h2d_engine && !getenv("MS_SDMA_ENGINE_H2D")) {   // none was free when the device was bound: ask again
+      std::lock_guard<std::mutex> lk(mu);
+      uint32_t avail = 0, pref = 0;
+      f_status(g.agent, cpu, &avail);
+      if (f_pref) f_pref(g.agent, cpu, &pref);
+      const uint32_t m = (pref & avail) ? (pref & avail) : (avail ? avail : pref);
+      g.h2d_engine = m ? (m & (~m + 1)) : 0;
+    }
+    return g.h2d_engine;
+  }
   // page-locked host memory -> device memory of `gpu_index`
   int copy_h2d(int gpu_index, void* dst_dev, const void* src_host, size_t n, Signal sig, unsigned engine) {
     f_sig_store(sig, 1);

@@ -63,3 +63,24 @@ def test_failing_rank_fails_the_launcher():
     env.pop("WORLD_SIZE", None)
     cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--emu", "--log-rows", "40"], env=env, capture_output=True, text=True, timeout=300)
     assert cp.returncode != 0 and not [l for l in cp.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_failing_lane_fails_the_run():
+    """A lane thread that dies (e.g. MS_ERR_NOMEM with too many proofs in flight) must fail the timed run - r04: eight 2^24-row provers ran out of HBM, their threads
+    died, and the run still printed a (doubled) proofs/s figure.  Lanes.run re-raises the first lane error."""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    ln = bench.Lanes(0, 5, 8, 3, 0, torch.device("cpu"), lib=bench.EMU_LIB)
+    ln.run(1)                                   # healthy: no error
+    orig = ln._prove_n
+
+    def flaky(i, n):
+        if i == 1:
+            raise RuntimeError("ministark error -7: out of memory")
+        return orig(i, n)
+    ln._prove_n = flaky
+    with pytest.raises(RuntimeError, match="lane 1 of 3 failed"):
+        ln.run(1)
+    ln.close()
