@@ -12,4 +12,9 @@ python tools/asan_cases.py
 ( cd tests && python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29931 shard_worker.py 0 8 8 16 2>&1 | grep -E '^\{|ERROR|runtime error' )
 ( cd tests && python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29932 shard_worker.py 1 8 4 16 2>&1 | grep -E '^\{|ERROR|runtime error' )
 ( cd tests && MS_SHARD_SLICES=4 MS_SHARD_SLICE_MIN=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29933 shard_worker.py 0 9 8 16 2>&1 | grep -E '^\{|ERROR|runtime error' )   # sliced digest exchange
+# r04: distributed round polynomials - proof assembled on rank 0, base-field DEEP points (gather fallback), half-empty coefficient ranges, multi-level scans with chunked proof gathers
+( cd tests && python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29934 shard_worker.py 0 9 8 16 root-only 2>&1 | grep -E '^\{|ERROR|runtime error' )
+( cd tests && python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29935 shard_worker.py 1 8 8 16 base-z 2>&1 | grep -E '^\{|ERROR|runtime error' )
+( cd tests && python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29936 shard_worker.py 0 10 8 16 low-degree 2>&1 | grep -E '^\{|ERROR|runtime error' )
+( cd tests && MS_SHARD_GATHER_CHUNK=2048 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29937 shard_worker.py 0 13 8 16 2>&1 | grep -E '^\{|ERROR|runtime error' )
 echo "sanitizer run clean"

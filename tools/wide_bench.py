@@ -49,6 +49,19 @@ for it in range(a.proofs + 1):
         assert stage("fri_fold_commit", lambda: ctx.fri_fold_commit([r2.next() % P, r2.next() % P]))[0] == 0
     assert stage("fri_query", lambda: ctx.fri_query([r2.next()], read=False))[0] == 0
 el = time.perf_counter() - t0
+import ctypes as C
+buf = C.create_string_buffer(1 << 15)
+ctx.check(ctx.L.ms_profile_begin(ctx.h))
+r2 = SplitMix64(6)
+ctx.trace_commit_device(d_trace.data_ptr(), N, w, 2 * w); ctx.interpolate()
+[ctx.check(ctx.polys_lincomb(sc, idx)) for sc, idx in combos]
+ctx.lde_commit(a.blowup, r2.next() % P or 3, 2 * w)
+ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
+prof = json.loads(buf.value.decode())
+prof.pop("shard", None)
+variants = prof.pop("ntt_pass_variants")
 print(json.dumps({"workload": f"wide AIR w={w} c={2 * w}, Goldilocks, 2^{a.log_rows} rows, blowup {a.blowup}", "proofs": a.proofs, "s_per_proof": el / a.proofs,
                   "proofs_per_s": a.proofs / el, "stage_ms_per_proof": {k: round(v / a.proofs * 1e3, 2) for k, v in times.items()},
-                  "hbm_gib_allocated": round(torch.cuda.mem_get_info()[1] / 2**30 - torch.cuda.mem_get_info()[0] / 2**30, 1)}))
+                  "hbm_gib_allocated": round(torch.cuda.mem_get_info()[1] / 2**30 - torch.cuda.mem_get_info()[0] / 2**30, 1),
+                  "kernel_ms_trace_commit_to_lde_commit": {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]},
+                  "ntt_variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "alg_GBps": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in variants.items()}}))
