@@ -556,3 +556,43 @@ def test_prove_several_padding_rows(mk, field, log_n, steps):
 @pytest.mark.parametrize("log_n,blowup", [(10, 16), (14, 16), (12, 32), (16, 16)])
 def test_coset_lde_other_blowups(mk, field, log_n, blowup):
     pc.case_coset_lde(mk, field, log_n, blowup)
+
+
+@pytest.mark.parametrize("upload", ["sdma", "hip"])
+def test_trace_upload_from_page_locked_memory(monkeypatch, upload):
+    """The other bulk transfer of the boundary: a trace handed over in page-locked host memory (ms_pinned_alloc) travels on an SDMA engine through the HSA runtime
+    (MS_UPLOAD=sdma, the default) or by hipMemcpyAsync (hip) - same trace root, same LDE root, same DEEP values as from a pageable numpy array."""
+    import ctypes as C
+    monkeypatch.setenv("MS_UPLOAD", upload)
+    ctx = ms.Context(0)
+    N, w = 1 << 18, 3
+    trace = fibonacci_trace_fast(0, N)
+    rc, want_root = ctx.trace_commit(trace, 6)          # pageable source
+    assert rc == 0
+    ctx.L.ms_pinned_alloc.restype = C.c_void_p
+    ctx.L.ms_pinned_free.argtypes = [C.c_void_p]
+    p = ctx.L.ms_pinned_alloc(C.c_size_t(N * w * 8))
+    assert p
+    try:
+        C.memmove(p, trace.ctypes.data, N * w * 8)
+        root = (C.c_uint8 * 32)()
+        for _ in range(2):                               # twice: the second upload overwrites a device buffer the first proof's kernels have read
+            assert ctx.L.ms_trace_commit(ctx.h, C.c_void_p(p), C.c_size_t(N), C.c_size_t(w), C.c_size_t(6), root) == 0, ctx.last_error()
+            assert bytes(root) == want_root
+        ctx.N, ctx.w = N, w
+        assert ctx.interpolate() == 0
+        for sc, idx in fibonacci_closures(0, N, orc.root_of_unity(0, N)):
+            assert ctx.polys_lincomb(sc, idx) == 0
+        rc, lde_root = ctx.lde_commit(8, 12345, 6)
+        c2 = ms.Context(0)
+        assert c2.trace_commit(trace, 6)[0] == 0 and c2.interpolate() == 0
+        for sc, idx in fibonacci_closures(0, N, orc.root_of_unity(0, N)):
+            assert c2.polys_lincomb(sc, idx) == 0
+        assert rc == 0 and c2.lde_commit(8, 12345, 6) == (0, lde_root)
+        # a non-canonical element in page-locked memory is still refused (the range check runs in the transposing kernel)
+        bad = trace.copy(); bad[7, 1] = MODULUS[0] + 5
+        C.memmove(p, bad.ctypes.data, N * w * 8)
+        assert ctx.L.ms_trace_commit(ctx.h, C.c_void_p(p), C.c_size_t(N), C.c_size_t(w), C.c_size_t(6), root) == ms.ERR_ARG
+    finally:
+        ctx.close()
+        ctx.L.ms_pinned_free(C.c_void_p(p))
