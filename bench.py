@@ -18,10 +18,14 @@ Rank 0 prints ONE JSON line.  Besides the headline it carries
   roofline       per-kernel HIP-event timing of the dominant NTT pass kernel vs its algorithmic bytes
   roofline_valu  the SHA-256 kernels (59 % of the kernel time) against the VALU issue roofline
   sharded        N > 1 only: ONE 2^24-row proof (BASELINE configs[3]) computed by all ranks together (ms_set_shard_rccl:
-                 coset-partitioned LDE/FRI + leaf hashing, RCCL digest all-to-all + root all-gather inside the library;
-                 strong scaling), in a child process per rank so that neither a hang nor a crash there can take the headline down
+                 coset-partitioned LDE/FRI + leaf hashing, RCCL digest all-to-all + root all-gather inside the library; r04: the
+                 coefficient-domain work by coefficient range, the FRI proof assembled on rank 0; strong scaling), in a child process
+                 per rank so that neither a hang nor a crash there can take the headline down; reports collective calls, bytes,
+                 distributed rounds, partitioned / replicated kernel time (HIP events) and matches_unsharded
   extra          N == 1 only: 2^24-row Goldilocks and 2^20-row BabyBear+Fp4 proofs/s, NTT-only GB/s at 2^20 and 2^24 rows,
-                 and `value_with_io` (trace from pinned host memory, FRI proof read back, overlapped over the in-flight lanes)
+                 `value_with_io` (trace from pinned host memory, FRI proof read back, both on SDMA engines, overlapped over the
+                 in-flight lanes) and `io_paired` (resident and I/O-inclusive rates alternated: the ratio to quote)
+  value_with_io  N == 1 only, top level: the I/O-inclusive rate beside `value` (the contract keeps `value` = traces resident in HBM)
   cpu_baseline   N == 1 only: the CPU oracle ("port") on the same 2^20-row proof, 1 thread and OpenMP
 `--mode shard` makes the sharded proof the timed step instead (the latency configuration for single large proofs).
 """
