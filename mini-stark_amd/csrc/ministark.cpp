@@ -1058,6 +1058,10 @@ template <class F> struct Ctx : CtxBase {
     void* badw;
     RQ(zero_alloc(4, &badw));  // device input cannot be range-checked on the host: the kernel flags elements >= p
     typename mspoly::TransposeInKernel<F>::Params tp{dsrc, d_polys.as<T>(), N, w, N, rinv, trace_mont, reinterpret_cast<u32*>(badw)};
+    if (w >= 16 && N >= 64) {   // wide traces: 64 x 64 tiles through LDS (coalesced both ways)
+      typedef mspoly::TransposeInTiledKernel<F> TK;
+      CK(run<TK>(K_TRANSPOSE, (unsigned)(N / TK::TILE), (unsigned)((w + TK::TILE - 1) / TK::TILE), TK::THREADS, TK::lds_bytes(), tp));
+    } else
     CK(run<mspoly::TransposeInKernel<F>>(K_TRANSPOSE, grid1(N * w, mspoly::THREADS), 1, mspoly::THREADS, 0, tp));
     // element f of trace.get_data() = column f % w, row f / w of the column-major copy
     // one proof over several ranks: every rank holds the whole trace, so rank k hashes the contiguous leaf groups [k*M/W, (k+1)*M/W) and only the W subtree roots travel (r04)

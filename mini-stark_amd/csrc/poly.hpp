@@ -39,6 +39,40 @@ template <class F> struct TransposeInKernel {
     p.dst[col * p.dst_stride + row] = v;
   }
 };
+// The same for WIDE traces (r04: the 64-column AIR of BASELINE configs[4]): with one thread per element the writes of a wave scatter over 64 columns, 8 bytes each
+// (3.8 ms for 2^22 rows x 64 columns = 4.4 x what the bytes cost); here a workgroup moves a 64 x 64 tile through LDS - rows in as 512-byte runs, columns out as
+// 512-byte runs.  Grid: (rows / 64, ceil(w / 64)).
+template <class F> struct TransposeInTiledKernel {
+  typedef typename F::T T;
+  static constexpr int THREADS = 256, TILE = 64;
+  typedef typename TransposeInKernel<F>::Params Params;
+  static MS_HD int nphases(const Params&) { return 2; }
+  static MS_HD size_t lds_bytes() { return (size_t)TILE * (TILE + 1) * sizeof(T); }
+  static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int nthreads, unsigned char* lds) {
+    T* tile = reinterpret_cast<T*>(lds);   // [col][row], pitch TILE + 1
+    const size_t row0 = (size_t)bx * TILE, col0 = (size_t)by * TILE;
+    if (ph == 0) {
+      for (int idx = tid; idx < TILE * TILE; idx += nthreads) {
+        const int r = idx / TILE, c = idx % TILE;
+        const size_t row = row0 + r, col = col0 + c;
+        if (row >= p.N || col >= p.w) continue;
+        const u64 raw = p.src[row * p.w + col];
+        const bool oob = raw >= F::P;
+        if (oob && p.bad) *p.bad = 1;
+        T v = F::from_u64(oob ? 0 : raw);
+        if (p.mont) v = F::mul(v, p.rinv);
+        tile[c * (TILE + 1) + r] = v;
+      }
+      return;
+    }
+    for (int idx = tid; idx < TILE * TILE; idx += nthreads) {
+      const int c = idx / TILE, r = idx % TILE;
+      const size_t row = row0 + r, col = col0 + c;
+      if (row >= p.N || col >= p.w) continue;
+      p.dst[col * p.dst_stride + row] = tile[c * (TILE + 1) + r];
+    }
+  }
+};
 // plain widening / narrowing copies between the u64 ABI and device storage
 template <class F> struct NarrowKernel {
   typedef typename F::T T;
