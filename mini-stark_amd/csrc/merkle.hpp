@@ -383,6 +383,7 @@ template <class F, int E, bool LAZY = false> struct LeafHashKernel {
     // every peer's chunk of a sharded commitment: its digests can travel while the next slice is hashed)
     size_t g_first; u32 run_len, run_stride;
     const LinColSpec* lin;   // per column of the matrix (width entries), or nullptr: no virtual columns
+    size_t out_g0;           // the digest of group g goes to nodes[g - out_g0] (a rank hashing the contiguous groups [out_g0, out_g0 + ngroups) of data every rank holds)
   };
   static constexpr int MAX_BYTES = F::MAX_DIGITS + Affix<E>::MAX_BYTES;  // appended between two drains
   static constexpr int MAXW = (3 + MAX_BYTES + 3) / 4 + 1;               // words one iteration can touch past the write position
@@ -430,15 +431,16 @@ template <class F, int E, bool LAZY = false> struct LeafHashKernel {
     }
     const u32 list = (u32)bx % (u32)OVF_LISTS;
     const u32 slot = msrt::wave_alloc_slot(p.ovf_count + list, deferred);
+    const size_t go = g - p.out_g0;   // digest slot
     if (deferred) {
       u32* e = p.ovf + ((size_t)list * p.ovf_cap + slot) * OVF_WORDS;
-      e[0] = (u32)g; e[1] = msg_bytes * 8u;
-      u32* st = p.nodes + g * 8;  // the state is parked in the digest slot
+      e[0] = (u32)go; e[1] = msg_bytes * 8u;
+      u32* st = p.nodes + go * 8;  // the state is parked in the digest slot
 #pragma unroll
       for (int i = 0; i < 8; i++) st[i] = s.h.st[i];
       return;
     }
-    uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + g * 8);
+    uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + go * 8);
     uint4_t o0, o1;
     o0.x = bswap32(s.h.st[0]); o0.y = bswap32(s.h.st[1]); o0.z = bswap32(s.h.st[2]); o0.w = bswap32(s.h.st[3]);
     o1.x = bswap32(s.h.st[4]); o1.y = bswap32(s.h.st[5]); o1.z = bswap32(s.h.st[6]); o1.w = bswap32(s.h.st[7]);

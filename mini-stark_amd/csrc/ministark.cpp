@@ -732,7 +732,7 @@ template <class F> struct Ctx : CtxBase {
   // leaf-group digests of `ngroups` groups into `out`: LeafHashKernel + the compacted pad-only blocks it deferred
   template <int EL>
   int leaf_hash(const T* base, size_t col_stride, size_t row_stride, size_t limb_stride, u32 width, size_t lpn, size_t ngroups, u32* out,
-                size_t g_first = 0, u32 run_len = 0, u32 run_stride = 0, const msmerkle::LinColSpec* lin = nullptr) {
+                size_t g_first = 0, u32 run_len = 0, u32 run_stride = 0, const msmerkle::LinColSpec* lin = nullptr, size_t out_g0 = 0) {
     if (ngroups >> 32) return fail(MS_ERR_SHAPE, "more than 2^32 leaf groups");
     // deferred pad-only blocks: OVF_LISTS lists, list l fed by the workgroups bx = l (mod OVF_LISTS); capacity = all their threads
     const size_t nwg = grid1(ngroups, msmerkle::THREADS), lists = msmerkle::OVF_LISTS;
@@ -744,14 +744,14 @@ template <class F> struct Ctx : CtxBase {
     lp.base = base; lp.col_stride = col_stride; lp.row_stride = row_stride; lp.limb_stride = limb_stride;
     lp.width = width; lp.lpn = (u32)lpn; lp.zero_as_empty = zae; lp.ngroups = ngroups; lp.nodes = out;
     lp.ovf_count = reinterpret_cast<u32*>(counters); lp.ovf = d_ovf.as<u32>(); lp.ovf_cap = (u32)cap;
-    lp.g_first = g_first; lp.run_len = run_len; lp.run_stride = run_stride; lp.lin = lin;
+    lp.g_first = g_first; lp.run_len = run_len; lp.run_stride = run_stride; lp.lin = lin; lp.out_g0 = out_g0;
     next_bytes = (double)ngroups * (lpn * EL * sizeof(T) + 32);
     if (lpn * EL >= (size_t)leaf_lazy_min) {  // long messages (wide rows): the two-block buffer that compresses wave-synchronously
       typedef msmerkle::LeafHashKernel<F, EL, true> LK;
       typename LK::Params ll;
       ll.base = lp.base; ll.col_stride = lp.col_stride; ll.row_stride = lp.row_stride; ll.limb_stride = lp.limb_stride; ll.width = lp.width; ll.lpn = lp.lpn;
       ll.zero_as_empty = lp.zero_as_empty; ll.ngroups = lp.ngroups; ll.nodes = lp.nodes; ll.ovf_count = lp.ovf_count; ll.ovf = lp.ovf; ll.ovf_cap = lp.ovf_cap;
-      ll.g_first = g_first; ll.run_len = run_len; ll.run_stride = run_stride; ll.lin = lin;
+      ll.g_first = g_first; ll.run_len = run_len; ll.run_stride = run_stride; ll.lin = lin; ll.out_g0 = out_g0;
       CK(run<LK>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, LK::lds_bytes(), ll));
     } else
     CK(run<msmerkle::LeafHashKernel<F, EL>>(K_LEAF_HASH, grid1(ngroups, msmerkle::THREADS), 1, msmerkle::THREADS, msmerkle::LeafHashKernel<F, EL>::lds_bytes(), lp));
@@ -857,10 +857,9 @@ template <class F> struct Ctx : CtxBase {
     const size_t W = (size_t)sh_world, M = ts.leaf_num / ts.lpn, Mloc = M / W;
     if (ts.ic != 2 || Mloc == 0 || (Mloc >> 32)) return fail(MS_ERR_STATE, "sharded tree needs a binary tree with at least world leaf groups");
     if (nodes.ensure((2 * Mloc - 1 + 2 * W - 1) * 32)) return fail(MS_ERR_NOMEM, "merkle nodes");
-    // group g of the launch is leaf group rank*Mloc + g (one run of Mloc groups); its digest lands at nodes[g]: the kernel indexes `nodes` by the global group
-    u32* out = nodes.as<u32>() - (size_t)sh_rank * Mloc * 8;
+    // group g of the launch is leaf group rank*Mloc + g (one run of Mloc groups); its digest lands at nodes[g] (out_g0 = the rank's first group)
     PartScope part(this);
-    RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, out, (size_t)sh_rank * Mloc, (u32)Mloc, 0)));
+    RQ((leaf_hash<EL>(base, col_stride, row_stride, limb_stride, width, ts.lpn, Mloc, nodes.as<u32>(), (size_t)sh_rank * Mloc, (u32)Mloc, 0, nullptr, (size_t)sh_rank * Mloc)));
     return finish_sharded_tree(ts, nodes, Mloc);
   }
   // root of the tree built LAST on this context (every caller reads it right behind the build)

@@ -22,8 +22,7 @@ def run_world(world, field, log_n, blowup, min_leaves, port, env=None, mode=""):
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("world,field,log_n,blowup", [(2, 0, 8, 8), (4, 0, 9, 8), (2, 1, 7, 8), (4, 1, 8, 4), (2, 0, 6, 2), (8, 0, 10, 8), (8, 1, 9, 8),
-                                                       (4, 1, 9, 16), (8, 0, 9, 16), (4, 0, 10, 2)])
+@pytest.mark.parametrize("world,field,log_n,blowup", [(2, 0, 8, 8), (4, 0, 9, 8), (2, 1, 7, 8), (8, 0, 10, 8), (8, 1, 9, 8), (4, 1, 9, 16), (4, 0, 10, 2)])
 def test_sharded_proof_matches_oracle(world, field, log_n, blowup):
     res = run_world(world, field, log_n, blowup, 16, 29800 + world * 10 + field * 3 + log_n)
     assert res["world"] == world
@@ -35,7 +34,7 @@ def test_sharded_proof_matches_oracle(world, field, log_n, blowup):
     assert res["dist_rounds"] >= 2
 
 
-@pytest.mark.parametrize("world,field,log_n", [(2, 0, 8), (4, 1, 8)])
+@pytest.mark.parametrize("world,field,log_n", [(4, 1, 8)])
 def test_sharded_proof_with_replicated_coefficient_work(world, field, log_n):
     """MS_SHARD_DIST=0: the r03 scheme (only the evaluation-domain work of the commitments is partitioned) still gives the oracle's bytes."""
     res = run_world(world, field, log_n, 8, 16, 29600 + world * 10 + field * 3 + log_n, env={"MS_SHARD_DIST": "0"})
@@ -43,7 +42,7 @@ def test_sharded_proof_with_replicated_coefficient_work(world, field, log_n):
     assert calls[0] >= 3 and calls[1] == calls[0] and calls[2] == 1 and calls[3] == 1 and res["dist_rounds"] == 0
 
 
-@pytest.mark.parametrize("world,field,log_n", [(2, 0, 8), (4, 0, 9), (8, 1, 9)])
+@pytest.mark.parametrize("world,field,log_n", [(4, 0, 9), (8, 1, 9)])
 def test_sharded_proof_assembled_on_rank0_only(world, field, log_n):
     """ms_shard_proof_on_root: the ranks' slices of the quotient polynomials are GATHERED to rank 0 (MS_XCHG_GATHER) instead of all-gathered; rank 0's proof
     equals the oracle's, the other ranks hold none; every other stage output is still identical on every rank."""
@@ -51,7 +50,7 @@ def test_sharded_proof_assembled_on_rank0_only(world, field, log_n):
     assert res["world"] == world and res["root_only"] is True
 
 
-@pytest.mark.parametrize("world,field,log_n", [(2, 0, 8), (4, 1, 8)])
+@pytest.mark.parametrize("world,field,log_n", [(2, 0, 8), (4, 1, 8)][1:])
 def test_sharded_proof_with_base_field_deep_points(world, field, log_n):
     """A DEEP point in the base field makes the evaluation-domain fold impossible (x^2 - z can vanish): the codeword of that round comes from a transform of
     the round polynomial, which for a DISTRIBUTED polynomial means gathering its parts first (round_commit's fallback)."""
@@ -65,7 +64,7 @@ def test_small_proof_stays_replicated():
     assert calls[0] == 0 and calls[1] == 0  # nothing reaches MS_SHARD_MIN_LEAVES: no commitment exchange
 
 
-@pytest.mark.parametrize("world,field,log_n,slices", [(2, 0, 8, 4), (4, 0, 9, 2), (8, 0, 10, 4), (2, 1, 8, 8)])
+@pytest.mark.parametrize("world,field,log_n,slices", [(8, 0, 10, 4), (2, 1, 8, 8)])
 def test_sliced_digest_exchange_matches_oracle(world, field, log_n, slices):
     """r03: large commitments hash their leaf groups in MS_SHARD_SLICES slices (slice s = the s-th part of every peer's chunk) so that the digests of a slice
     travel while the next slice is hashed (RCCL: on the context's communication stream; here: the callback, op ALL_TO_ALL_SLICE with the strided layout of
@@ -75,8 +74,8 @@ def test_sliced_digest_exchange_matches_oracle(world, field, log_n, slices):
     assert res["slices"] >= slices and calls[0] >= 1 and calls[1] >= calls[0]
 
 
-@pytest.mark.parametrize("world,field,log_n,env,mode", [(2, 0, 14, {}, ""), (2, 1, 14, {}, ""), (4, 0, 14, {"MS_SHARD_GATHER_CHUNK": "4096"}, ""),
-                                                       (2, 0, 12, {"MS_SHARD_GATHER_CHUNK": "1024"}, "root-only"), (8, 0, 13, {"MS_SHARD_GATHER_CHUNK": "8192"}, "")])
+@pytest.mark.parametrize("world,field,log_n,env,mode", [(2, 1, 14, {}, ""), (4, 0, 14, {"MS_SHARD_GATHER_CHUNK": "4096"}, ""),
+                                                       (2, 0, 12, {"MS_SHARD_GATHER_CHUNK": "1024"}, "root-only")])
 def test_sharded_multilevel_scans_and_chunked_proof_gather(world, field, log_n, env, mode):
     """Ranks whose coefficient ranges exceed one block of the suffix scan (2048 elements: the carry-in from the higher ranks then travels down the scan's levels), and
     proof slices that cross the exchange buffer in several pieces (MS_SHARD_GATHER_CHUNK forces small pieces), all-gathered and gathered to rank 0."""
@@ -84,7 +83,7 @@ def test_sharded_multilevel_scans_and_chunked_proof_gather(world, field, log_n, 
     assert res["world"] == world and res["dist_rounds"] >= 8
 
 
-@pytest.mark.parametrize("world,field,log_n", [(4, 0, 9), (8, 0, 11), (8, 1, 10), (2, 1, 8)])
+@pytest.mark.parametrize("world,field,log_n", [(8, 0, 11), (2, 1, 8)])
 def test_sharded_proof_with_half_empty_coefficient_ranges(world, field, log_n):
     """Trace polynomials of degree N/2 + 2: FRI's round-0 domain is sized for N coefficients but the polynomial has N/2 + 3, so the upper ranks' coefficient ranges are
     empty and one rank holds the ragged top - empty scan jobs, zero aggregates in the carry chain, slices of length zero in the proof gather."""
