@@ -244,6 +244,7 @@ class Lanes:
 
 def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
     """ONE proof per step computed by all ranks together; the collectives run inside the library (RCCL) unless --backend gloo."""
+    import numpy as np
     import torch
     import mini_stark_amd as ms
     from mini_stark_amd.stark import StarkConfig, fibonacci_air
@@ -288,6 +289,32 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
     prove(1)
     ctx.check(ctx.L.ms_profile_end(ctx.h, buf, C.c_size_t(len(buf))))
     shard_prof = json.loads(buf.value.decode()).get("shard", {})
+    # ... and one more through the stage functions one by one (fixed challenges, every rank the same calls): host-visible milliseconds per stage of the sharded proof,
+    # what a first real multi-GPU run needs to see where the time goes (collectives included)
+    stage_ms = {}
+    try:
+        from mini_stark_amd.synthetic import SplitMix64
+        P, e = (2**64 - 2**32 + 1, 2) if args.field == 0 else (2013265921, 4)
+        rng = SplitMix64(99)
+
+        def st(name, fn):
+            t = time.perf_counter(); r = fn(); stage_ms[name] = stage_ms.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+            return r
+        ctx.check(st("trace_commit", lambda: ctx.trace_commit_device(d_trace.data_ptr(), N, 3, tt.constrain_number()))[0])
+        ctx.check(st("interpolate", ctx.interpolate))
+        for sc, idx in tt.transitions:
+            ctx.check(st("polys_lincomb", lambda: ctx.polys_lincomb(sc, idx)))
+        ctx.check(st("lde_commit", lambda: ctx.lde_commit(args.blowup, rng.next() % P or 3, tt.constrain_number()))[0])
+        ctx.check(st("mix", lambda: ctx.mix(rng.next() % P)))
+        ctx.check(st("eval_ext", lambda: ctx.eval_ext(np.array([rng.next() % P for _ in range(e)], dtype=np.uint64)))[0])
+        ctx.check(st("fri_begin", lambda: ctx.fri_begin(args.blowup, cfg.rounds))[0])
+        for _ in range(1, cfg.rounds):
+            ctx.check(st("fri_deep", lambda: ctx.fri_deep([rng.next() % P for _ in range(e)]))[0])
+            ctx.check(st("fri_fold_commit", lambda: ctx.fri_fold_commit([rng.next() % P for _ in range(e)]))[0])
+        ctx.check(st("fri_query", lambda: ctx.fri_query([rng.next() for _ in range(cfg.fri_queries)], read=False))[0])
+        stage_ms = {k: round(v, 3) for k, v in stage_ms.items()}
+    except Exception as ex:  # noqa: BLE001 - a diagnostic must not take the leg down
+        stage_ms = {"error": f"{type(ex).__name__}: {ex}"}
     # the same trace proved UNSHARDED by rank 0 on a second context: pins the exchange path (a symmetric error - wrong chunk order in the
     # all-to-all, a mistake in the in-place all-reduce - gives every rank the same wrong root and would pass `all_ranks_same_final_root`)
     matches = None
@@ -313,6 +340,7 @@ def sharded_leg(args, grp, local_rank, log_rows, steps, warmup):
            "distributed_rounds": dist_rounds, "rounds": cfg.rounds, "fri_proof_assembled_on": "rank 0 only (ms_shard_proof_on_root)",
            "digest_exchange_slices": int(os.environ.get("MS_SHARD_SLICES", "1" if args.backend == "nccl" else "4")),
            "partitioned_ms_estimate": shard_prof.get("partitioned_ms"), "replicated_ms_estimate": shard_prof.get("replicated_ms"),
+           "replicated_ms_by_kernel": shard_prof.get("replicated_by_kernel"), "stage_ms_rank0_one_proof": stage_ms,
            "replicated_ms_note": "rank 0, one extra proof with per-launch HIP events (they add launch overhead): kernel time of launches that work on this rank's 1/world part of the proof "
                                  "(partitioned) and of launches every rank repeats (replicated: INTT, constraint polynomials, mix, tree tops, commitments below MS_SHARD_MIN_LEAVES); "
                                  "DESIGN.md 5"}
