@@ -101,6 +101,8 @@ int ms_shard_slice_layout(ms_ctx* ctx, size_t* offset, size_t* stride);
  * ms_set_shard above stays as the seam for callers without RCCL (the gloo tests on the kernel-emulation build). */
 int ms_rccl_unique_id(uint8_t out[128]);
 int ms_set_shard_rccl(ms_ctx* ctx, int rank, int world, const uint8_t unique_id[128], size_t cap_bytes);
+/* (tests: with env MS_SHARD_WORLD1=1 at ms_create, ms_set_shard / ms_set_shard_rccl accept world = 1 WITH buffers / a unique id and run the sharded code paths on that one
+ * rank - every exchange a transfer to itself - so that the sharded kernels and, through ms_set_shard_rccl, the RCCL calls execute through whole proofs on one GPU.) */
 /* the four collectives on a ONE-rank RCCL communicator with known payloads: checks the run-time binding (symbols, enums, the
  * by-value ncclUniqueId) and the stream ordering on a single GPU */
 int ms_rccl_selftest(ms_ctx* ctx);

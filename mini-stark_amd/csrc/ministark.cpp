@@ -125,6 +125,9 @@ template <class F> struct Ctx : CtxBase {
 
   // ---- one proof sharded over `sh_world` ranks (ms_set_shard; include/ministark.h)
   int sh_rank = 0, sh_world = 1;
+  // sh_on: the sharded code paths are active.  Normally that is world > 1; with MS_SHARD_WORLD1=1 (tests) a ONE-rank "world" runs them too - every exchange degenerates to a
+  // transfer to itself, but every kernel, buffer offset, stream ordering and RCCL call of the sharded prover executes, through whole proofs, on one GPU
+  bool sh_on = false; int allow_w1 = 0;
   u8* xs = nullptr; u8* xr = nullptr; size_t xcap = 0;   // caller-owned exchange buffers (device)
   ms_exchange_fn xfn = nullptr; void* xuser = nullptr;
   size_t shard_min_leaves = 32768;                        // MS_SHARD_MIN_LEAVES: smaller commitments stay replicated
@@ -198,14 +201,14 @@ template <class F> struct Ctx : CtxBase {
     if (rccl_comm) { msrt::sync(stream); if (comm_stream) msrt::sync(comm_stream); msrt::Rccl::get().comm_destroy(rccl_comm); rccl_comm = nullptr; }   // (work may be queued on either stream)
     rccl_send.release(); rccl_recv.release();
   }
-  void unshard() { sh_rank = 0; sh_world = 1; xs = xr = nullptr; xcap = 0; xfn = nullptr; xuser = nullptr; have_lde = false; nrounds_done = 0; blob_size = 0; }
+  void unshard() { sh_on = false; sh_rank = 0; sh_world = 1; xs = xr = nullptr; xcap = 0; xfn = nullptr; xuser = nullptr; have_lde = false; nrounds_done = 0; blob_size = 0; }
   int set_shard_rccl(int rank, int world, const u8* unique_id, size_t cap) override {
     if (world < 1 || !is_pow2((u64)world) || rank < 0 || rank >= world) return fail(MS_ERR_ARG, "set_shard_rccl: world must be a power of two and 0 <= rank < world");
     // the old communicator and buffers go first; until the new ones are complete the context is UNSHARDED, so that a failure below
     // (no unique id, librccl missing, out of memory, ncclCommInitRank) cannot leave sh_world > 1 over freed buffers / a null callback
     drop_rccl();
     unshard();
-    if (world == 1) return MS_OK;
+    if (world == 1 && !(allow_w1 && unique_id && cap >= 4096)) return MS_OK;
     if (!unique_id || cap < 4096) return fail(MS_ERR_ARG, "set_shard_rccl: unique id / buffer capacity missing");
     msrt::Rccl& R = msrt::Rccl::get();
     if (R.load()) return fail(MS_ERR_HIP, "RCCL is not available (librccl.so could not be loaded; MS_RCCL_LIB names it)");
@@ -215,7 +218,7 @@ template <class F> struct Ctx : CtxBase {
     const int e = R.comm_init_rank(&comm, world, id, rank);
     if (e || !comm) { drop_rccl(); err = std::string("ncclCommInitRank failed: ") + (R.err_string ? R.err_string(e) : "?"); return MS_ERR_HIP; }
     rccl_comm = comm;
-    sh_rank = rank; sh_world = world; xs = rccl_send.as<u8>(); xr = rccl_recv.as<u8>(); xcap = cap;
+    sh_rank = rank; sh_world = world; xs = rccl_send.as<u8>(); xr = rccl_recv.as<u8>(); xcap = cap; sh_on = true;
     return MS_OK;
   }
   // The four collectives on a one-rank communicator (send/recv to self, all-gather, both all-reduces) with known payloads:
@@ -284,12 +287,13 @@ template <class F> struct Ctx : CtxBase {
   int shard_proof_is_elsewhere() const override { return (proof_root_only && sh_world > 1 && sh_rank != 0 && nrounds_done == fri_rounds && fri_rounds) ? 1 : 0; }
   int shard_round_is_distributed(int r) override { return (r >= 0 && (size_t)r < nrounds_done && rounds[r]->dist) ? 1 : 0; }
   int shard_stats(u64* out) override { if (!out) return fail(MS_ERR_ARG, "shard_stats"); memcpy(out, xstat, sizeof xstat); return MS_OK; }
-  bool shardable(size_t leaf_groups) const { return sh_world > 1 && leaf_groups >= shard_min_leaves && leaf_groups >= (size_t)sh_world * (size_t)sh_world; }
+  bool shardable(size_t leaf_groups) const { return sh_on && leaf_groups >= shard_min_leaves && leaf_groups >= (size_t)sh_world * (size_t)sh_world; }
   int set_shard(int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) override {
     if (world < 1 || !is_pow2((u64)world) || rank < 0 || rank >= world) return fail(MS_ERR_ARG, "set_shard: world must be a power of two and 0 <= rank < world");
     if (world > 1 && (!d_send || !d_recv || !fn || cap < 4096)) return fail(MS_ERR_ARG, "set_shard: exchange buffers / callback missing");
     drop_rccl();
     sh_rank = rank; sh_world = world; xs = reinterpret_cast<u8*>(d_send); xr = reinterpret_cast<u8*>(d_recv); xcap = cap; xfn = fn; xuser = user;
+    sh_on = world > 1 || (allow_w1 && d_send && d_recv && fn && cap >= 4096);
     have_lde = false; nrounds_done = 0; blob_size = 0;
     return MS_OK;
   }
@@ -912,7 +916,7 @@ template <class F> struct Ctx : CtxBase {
   size_t lcount(const Round* r, size_t n) const { const size_t lo = (size_t)sh_rank * r->S; return n <= lo ? 0 : (n - lo < r->S ? n - lo : r->S); }
   // chunk of a distributed round polynomial on a domain of D points (0: the round stays replicated): the commitment must be sharded and the chunk even
   size_t dist_chunk(size_t D) const {
-    if (sh_world <= 1 || !shard_dist || !fri_blowup || !shardable(D / 2)) return 0;
+    if (!sh_on || !shard_dist || !fri_blowup || !shardable(D / 2)) return 0;
     const size_t den = fri_blowup * (size_t)sh_world;
     if (D % den) return 0;
     const size_t S = D / den;
@@ -967,6 +971,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_NTT_FAST_MAX")) ntt_fast_max = atoi(e);
     if (const char* e = getenv("MS_SHARD_MIN_LEAVES")) { long v = atol(e); if (v >= 1) shard_min_leaves = (size_t)v; }
     if (const char* e = getenv("MS_SHARD_DIST")) shard_dist = atoi(e);
+    if (const char* e = getenv("MS_SHARD_WORLD1")) allow_w1 = atoi(e);
     if (const char* e = getenv("MS_SHARD_GATHER_CHUNK")) { long v = atol(e); if (v >= 64) shard_gather_chunk = (size_t)v & ~(size_t)63; }
     if (const char* e = getenv("MS_SHARD_SLICES")) { int v = atoi(e); if (v >= 1 && v <= 64) { shard_slices = v; shard_slices_set = true; } }
     if (const char* e = getenv("MS_SHARD_SLICE_MIN")) { long v = atol(e); if (v >= 1) shard_slice_min = (size_t)v; }
@@ -1064,7 +1069,7 @@ template <class F> struct Ctx : CtxBase {
     CK(run<mspoly::TransposeInKernel<F>>(K_TRANSPOSE, grid1(N * w, mspoly::THREADS), 1, mspoly::THREADS, 0, tp));
     // element f of trace.get_data() = column f % w, row f / w of the column-major copy
     // one proof over several ranks: every rank holds the whole trace, so rank k hashes the contiguous leaf groups [k*M/W, (k+1)*M/W) and only the W subtree roots travel (r04)
-    if (sh_world > 1 && shard_dist && shardable(ts.leaf_num / ts.lpn)) RQ((tree_build_sharded_contiguous<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
+    if (sh_on && shard_dist && shardable(ts.leaf_num / ts.lpn)) RQ((tree_build_sharded_contiguous<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
     else
     RQ((tree_build<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
     trace_ts = ts;
@@ -1457,7 +1462,7 @@ template <class F> struct Ctx : CtxBase {
   }
   // DEEP-ALI evaluations by coefficient range (r04): rank k evaluates the coefficients [k*Sx, (k+1)*Sx) of every polynomial at every point, ONE all-gather of the partial
   // sums, and every rank combines them with z^Sx
-  bool dist_eval() const { return sh_world > 1 && shard_dist && N >= shard_min_leaves && N >= (size_t)sh_world * 2; }
+  bool dist_eval() const { return sh_on && shard_dist && N >= shard_min_leaves && N >= (size_t)sh_world * 2; }
   // the polynomials the DEEP-ALI kernels evaluate: those whose coefficients exist, then the validity polynomial (index npolys); the lazily defined ones get their
   // values on the host as the combination their provenance names (eval_finish)
   std::vector<int> eval_set() const { std::vector<int> ev; for (int i = 0; i < npolys; i++) if (poly_mat[i]) ev.push_back(i); ev.push_back(npolys); return ev; }
@@ -2040,7 +2045,7 @@ template <class F> struct Ctx : CtxBase {
     // Sharded proof (ms_set_shard): paths are staged in the exchange buffer — every byte written by exactly one rank
     // (replicated rounds: rank 0), summed over the ranks, then copied into the blob.
     typedef msmerkle::ShardPathJob<F, E> SPJ;
-    const bool shard = sh_world > 1;
+    const bool shard = sh_on;
     std::vector<FJ> fjobs(W); std::vector<PJ> pjobs; std::vector<SPJ> sjobs; std::vector<msmerkle::CopyJob> cjobs;
     size_t stage_bytes = 0;
     for (size_t i = 0; i < W; i++) {

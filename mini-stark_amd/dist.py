@@ -184,3 +184,41 @@ class ShardExchange:
 
     def close(self):
         self.ctx.set_shard(0, 1, 0, 0, 0, None)
+
+
+class LocalShard:
+    """The exchange callback of a ONE-rank "world" (env MS_SHARD_WORLD1=1 at ms_create; tests): every collective is a transfer to itself, done here with tensor copies
+    - no torch.distributed, no second process - so that every kernel and buffer layout of the sharded prover runs inside one process, against the oracle.
+    `rccl=True` instead joins a one-rank RCCL communicator inside the library (ms_set_shard_rccl): the RCCL calls themselves - grouped send / recv, all-gathers,
+    all-reduces, the sliced exchange on its own stream - then execute through whole proofs on one GPU."""
+
+    def __init__(self, ctx, cap_bytes: int, device=None, rccl: bool = False):
+        self.ctx, self.rccl = ctx, rccl
+        self.calls = {i: 0 for i in range(6)}
+        if rccl:
+            ctx.set_shard_rccl(0, 1, ctx.rccl_unique_id(), cap_bytes)
+            return
+        dev = device if device is not None else torch.device("cpu")
+        self.send = torch.zeros(cap_bytes, dtype=torch.uint8, device=dev)
+        self.recv = torch.zeros(cap_bytes, dtype=torch.uint8, device=dev)
+        ctx.set_shard(0, 1, self.send.data_ptr(), self.recv.data_ptr(), cap_bytes, self._exchange)
+
+    def _exchange(self, op, nbytes):
+        import ctypes as C
+        self.calls[op] += 1
+        if op in (0, 1, 5):          # all-to-all / all-gather / gather of one rank: its own payload comes back
+            self.recv[:nbytes].copy_(self.send[:nbytes])
+        elif op == 4:                # one slice of the sliced all-to-all
+            off, stride = C.c_size_t(0), C.c_size_t(0)
+            self.ctx.check(self.ctx.L.ms_shard_slice_layout(self.ctx.h, C.byref(off), C.byref(stride)))
+            self.recv[off.value: off.value + nbytes].copy_(self.send[off.value: off.value + nbytes])
+        # 2, 3: all-reduces over one rank leave the buffer as it is
+        if self.send.is_cuda:
+            torch.cuda.synchronize()
+        return 0
+
+    def close(self):
+        if self.rccl:
+            self.ctx.set_shard_rccl(0, 1, bytes(128), 0)
+        else:
+            self.ctx.set_shard(0, 1, 0, 0, 0, None)

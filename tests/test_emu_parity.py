@@ -347,3 +347,18 @@ def test_c_abi_never_unwinds(field):
     L.ms_destroy(h)
     # after all that the library still proves: same bytes as the oracle
     pc.case_prove(lambda f, fresh=False: ms.Context(f, lib_path=EMU), field, 4, 4, read_big=False)
+
+
+@pytest.mark.parametrize("field,log_n,blowup,env,root_only,base_z", [(0, 10, 8, {}, False, ()), (1, 9, 8, {"MS_SHARD_SLICES": "4", "MS_SHARD_SLICE_MIN": "1"}, False, (1, 2)),
+                                                                    (0, 13, 8, {"MS_SHARD_GATHER_CHUNK": "4096"}, True, ()), (0, 8, 2, {}, False, ())])
+def test_sharded_code_paths_on_one_rank(monkeypatch, field, log_n, blowup, env, root_only, base_z):
+    """r04: MS_SHARD_WORLD1=1 lets a one-rank world run the SHARDED prover (coset evaluation, digest exchange, subtree + top, distributed round polynomials with their carry
+    chain, query slices, paths through the exchange buffer) inside one process, every exchange a copy to itself: same bytes as the oracle.  The GPU suite runs the same case on
+    the real kernels and with RCCL doing the (self-)exchanges inside the library."""
+    monkeypatch.setenv("MS_SHARD_WORLD1", "1")
+    monkeypatch.setenv("MS_SHARD_MIN_LEAVES", "16")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+    st, dist_rounds = pc.case_sharded_paths_on_one_rank(lambda f: ms.Context(f, lib_path=EMU), field, log_n, blowup, root_only=root_only, base_z=base_z)
+    assert st[0] >= 3 and st[1] > st[0] and st[2] == 1 and st[3] == 1 and dist_rounds >= 2

@@ -596,3 +596,23 @@ def test_trace_upload_from_page_locked_memory(monkeypatch, upload):
     finally:
         ctx.close()
         ctx.L.ms_pinned_free(C.c_void_p(p))
+
+
+@pytest.mark.parametrize("field,log_n,rccl,env,root_only", [(0, 12, False, {}, False), (0, 16, True, {}, False), (1, 14, True, {"MS_SHARD_SLICES": "4", "MS_SHARD_SLICE_MIN": "64"}, True),
+                                                           (0, 18, True, {"MS_SHARD_SLICES": "4", "MS_SHARD_MIN_LEAVES": "32768"}, False)])
+def test_sharded_code_paths_on_one_rank_on_gpu(monkeypatch, field, log_n, rccl, env, root_only):
+    """The sharded prover on a one-rank world on the real kernels (MS_SHARD_WORLD1=1).  rccl=True: the exchanges are RCCL calls inside the library on a one-rank communicator -
+    grouped ncclSend / ncclRecv (to itself), ncclAllGather, ncclAllReduce, the sliced digest exchange on its own stream behind events, the gather to rank 0 - so the RCCL branch,
+    which no multi-GPU box has run yet, executes through whole proofs with real buffers and stream ordering, bit-exact against the oracle (2^18 rows with the default threshold)."""
+    import torch
+    monkeypatch.setenv("MS_SHARD_WORLD1", "1")
+    monkeypatch.setenv("MS_SHARD_MIN_LEAVES", "64")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    if log_n >= 16:
+        orc.set_threads(8)
+    try:
+        st, dist_rounds = pc.case_sharded_paths_on_one_rank(lambda f: ms.Context(f), field, log_n, 8, rccl=rccl, device=torch.device("cuda", 0), root_only=root_only)
+    finally:
+        orc.set_threads(1)
+    assert st[0] >= 3 and st[1] > st[0] and st[2] == 1 and st[3] == 1 and dist_rounds >= 2
