@@ -83,6 +83,32 @@ def one(world, dist):
 
 base = one(1, 1)
 print(json.dumps(base), flush=True)
+if os.environ.get("MS_PROBE_W1_RCCL") == "1":
+    # the sharded prover on a ONE-rank RCCL communicator (MS_SHARD_WORLD1): same work as the unsharded proof plus everything sharding adds on a rank - coset folds, digest
+    # interleaves, the extra launches of the distributed scans - and ~80 RCCL calls per proof (to itself): what the sharded STRUCTURE costs before any link is involved
+    from mini_stark_amd.dist import LocalShard
+    os.environ["MS_SHARD_WORLD1"] = "1"
+    for slices in ("1", "4"):
+        os.environ["MS_SHARD_SLICES"] = slices
+        ctx = ms.Context(0)
+        sh = LocalShard(ctx, 32 * N * blowup + (4 << 20), rccl=True)
+        ctx.shard_proof_on_root(True)
+        tt = fibonacci_air(ctx, N - 1)
+        hs = HostStark(ctx, 20, blowup, N - 1, tt.constrain_number())
+        d_trace = torch.from_numpy(tt.data.view(np.int64)).to(dev)
+        def prove():
+            ctx.check(hs.prove_raw(tt, trace_device_ptr=d_trace.data_ptr(), read_fri_proof=False))
+        prove(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(args.reps):
+            t0 = time.perf_counter(); prove(); ts.append((time.perf_counter() - t0) * 1e3)
+        st0 = ctx.shard_stats()
+        prove()
+        st1 = ctx.shard_stats()
+        print(json.dumps({"world": 1, "rccl_one_rank": True, "digest_exchange_slices": int(slices), "log_rows": args.log_rows, "ms_wall_min": round(min(ts), 3), "ms_wall_all": [round(t, 3) for t in ts],
+                          "overhead_vs_unsharded_ms": round(min(ts) - base["ms_wall_min"], 3), "collective_calls_per_proof": [st1[i] - st0[i] for i in range(4)]}), flush=True)
+        sh.close(); ctx.close()
+    del os.environ["MS_SHARD_WORLD1"], os.environ["MS_SHARD_SLICES"]
 for w in args.worlds:
     for d in args.dist:
         r = one(w, d)
