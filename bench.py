@@ -540,8 +540,8 @@ def main():
                            "variants": per_variant,
                            "all_ntt_pass_kernels": {"launches_per_proof": allp["launches"], "ms_per_proof": allp["ms"],
                                                     "alg_GBps": allp["alg_bytes"] / (allp["ms"] * 1e-3) / 1e9 if allp["ms"] else 0.0},
-                           "note": "these passes are not bound by HBM (a column resident in the Infinity Cache or an LDS-DMA prefetch of the next tile changes nothing: profiles/r02_*.log) but by how fast 4 waves per SIMD get "
-                                   "through 64-bit modular arithmetic on 32-bit lanes: r03 SQ counters (profiles/r03_sq_counters_ntt_passes.txt) give 79 / 125 VALU instructions per element (later / first pass; 96 / 139 in r02) "
+                           "note": "these passes are not bound by HBM (a column resident in the Infinity Cache or an LDS-DMA prefetch of the next tile changes nothing: profiles/HISTORY.md) but by how fast 4 waves per SIMD get "
+                                   "through 64-bit modular arithmetic on 32-bit lanes: SQ counters (profiles/r04_sq_counters_ntt_passes.txt; same kernels as r03) give 79 / 113-125 VALU instructions per element (later / first pass; 96 / 139 in r02) "
                                    "and 0.65 scalar instructions per vector one, issued at one VALU instruction per SIMD per ~9 clocks; DESIGN.md 6.2"}
         tot = sum(v["ms"] for v in prof.values()) or 1.0
         out["kernel_ms_per_proof"] = {n: round(v["ms"], 4) for n, v in prof.items() if v["launches"]}
