@@ -532,6 +532,68 @@ template <int IC> struct InnerHashKernelT {
 typedef InnerHashKernelT<0> InnerHashKernel;
 typedef InnerHashKernelT<2> InnerHashKernel2;
 
+// Binary-tree levels whose launches are latency, not throughput (a few thousand parents: far less than one wave per SIMD): workgroup b takes the 2^nlevels
+// children [b << nlevels, (b + 1) << nlevels) of the level at child_off and hashes the nlevels levels above them, 2^(nlevels-1), ..., 1 threads at work.  Every
+// node is written to its place in the level-major node array (the openings read them), but a level reads its children from LDS, as the state words the level
+// below left there (no byte swaps either), behind a barrier that orders LDS traffic only: a level costs 4.5 us (the two compressions of a lone wave: 4.1 us)
+// instead of the 6.0-6.3 us that one launch per level, or one workgroup walking the levels through global memory, took (r04 trace of one proof:
+// profiles/r04_small_round_kernels_ab.log).
+// nlevels <= MAX_LEVELS; grid = nchildren >> nlevels; host_root / aux as InnerHashKernelT.
+struct InnerSubtreeKernel {
+  static constexpr int THREADS = msmerkle::THREADS;
+  static constexpr int MAX_LEVELS = 9;
+  static_assert((1 << (MAX_LEVELS - 1)) == THREADS, "level 0 of a workgroup: one parent per thread");
+  typedef InnerHashParams Params;
+  static MS_HD size_t lds_bytes() { return (size_t)(THREADS + THREADS / 2) * 32; }
+  static MS_DEV void run(const Params& p, int bx, int, int, int tid, unsigned char* lds) {
+    u32* const buf0 = reinterpret_cast<u32*>(lds);          // levels 0, 2, 4, ...: <= THREADS digests
+    u32* const buf1 = buf0 + (size_t)THREADS * 8;           // levels 1, 3, ...: <= THREADS / 2 digests
+    const u32 nl = p.nlevels;
+    size_t child_off = p.child_off, nchildren = p.nchildren;
+    u32 pp = 1u << nl;
+    for (u32 l = 0; l < nl; l++) {
+      pp >>= 1;   // parents of this workgroup at this level
+      const size_t nparents = nchildren >> 1;
+      if ((u32)tid < pp) {
+        const size_t g = (size_t)bx * pp + (u32)tid;
+        Sha256 h; h.init();
+        u32 w[16];
+        if (l == 0) {
+          const uint4_t* c4 = reinterpret_cast<const uint4_t*>(p.nodes + (child_off + 2 * g) * 8);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint4_t v = c4[q];
+            w[4 * q] = bswap32(v.x); w[4 * q + 1] = bswap32(v.y); w[4 * q + 2] = bswap32(v.z); w[4 * q + 3] = bswap32(v.w);
+          }
+        } else {
+          const uint4_t* c4 = reinterpret_cast<const uint4_t*>(((l & 1) ? buf0 : buf1) + (size_t)tid * 16);
+#pragma unroll
+          for (int q = 0; q < 4; q++) { const uint4_t v = c4[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+        }
+        h.compress(w);
+        h.template compress_pad_block<512u>();
+        if (l + 1 < nl) {
+          uint4_t* o = reinterpret_cast<uint4_t*>(((l & 1) ? buf1 : buf0) + (size_t)tid * 8);
+          uint4_t s0, s1;
+          s0.x = h.st[0]; s0.y = h.st[1]; s0.z = h.st[2]; s0.w = h.st[3]; s1.x = h.st[4]; s1.y = h.st[5]; s1.z = h.st[6]; s1.w = h.st[7];
+          o[0] = s0; o[1] = s1;
+        }
+        uint4_t* out = reinterpret_cast<uint4_t*>(p.nodes + (child_off + nchildren + g) * 8);
+        uint4_t o0, o1;
+        o0.x = bswap32(h.st[0]); o0.y = bswap32(h.st[1]); o0.z = bswap32(h.st[2]); o0.w = bswap32(h.st[3]);
+        o1.x = bswap32(h.st[4]); o1.y = bswap32(h.st[5]); o1.z = bswap32(h.st[6]); o1.w = bswap32(h.st[7]);
+        out[0] = o0; out[1] = o1;
+        if (p.host_root && nparents == 1) {
+          uint4_t* hr = reinterpret_cast<uint4_t*>(p.host_root); hr[0] = o0; hr[1] = o1;
+          if (p.aux_src) { *p.aux_dst = *p.aux_src; *p.aux_src = 0; }
+        }
+      }
+      if (l + 1 < nl) msrt::wg_barrier();
+      child_off += nchildren; nchildren = nparents;
+    }
+  }
+};
+
 // MerklePath extraction (src/merkle.rs:216-288), one thread per opened leaf.  Each job names a
 // tree (FRI codeword view, width = 1) and the device word holding the leaf index; writes
 //   u64 leaf_index | lpn*E u64 limbs | u64 nlevels | nlevels * ic * 32 bytes      at out.

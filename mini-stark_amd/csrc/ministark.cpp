@@ -118,6 +118,10 @@ template <class F> struct Ctx : CtxBase {
                        // per Fibonacci proof alone, but 248 -> 240 proofs/s with 8 proofs in flight (five interleaved runs each)
   int tree_top_parents = msmerkle::THREADS;  // MS_TREE_TOP: levels of at most this many parents are walked by one workgroup in one launch (measured: 256 beats 1024 by 3 % in latency)
   int leaf_lazy_min = 16;  // MS_LEAF_LAZY_MIN: leaf groups of at least this many base limbs use the wave-synchronous two-block leaf kernel
+  size_t fold_small_max = 16384;   // MS_FOLD_SMALL_MAX
+  // MS_TREE_SUBTREE_PARENTS: binary-tree levels of at most this many parents run as subtree launches (msmerkle::InnerSubtreeKernel); 0: one launch per level + the fused top.
+  // Same-box A/B, 8 proofs in flight: 4096 -> +0.8 % over 0, 65536 -> -0.8 %; one proof in flight: +1.6 % with 65536 (profiles/r04_small_round_kernels_ab.log)
+  size_t subtree_parents = 4096;
   int fri_pointwise = 1;  // MS_FRI_POINTWISE=0: codewords of FRI rounds >= 1 by NTT of the round polynomial instead of the evaluation-domain fold
   msrt::Stream* own_stream = nullptr;
   msrt::Stream* stream = nullptr;
@@ -785,6 +789,20 @@ template <class F> struct Ctx : CtxBase {
       msmerkle::InnerHashKernel::Params ip;
       ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic; ip.host_root = nullptr; ip.aux_src = nullptr; ip.aux_dst = nullptr;
       const size_t nparents = nchildren / ic;
+      if (ic == 2 && nparents <= subtree_parents && (nchildren & (nchildren - 1)) == 0) {   // latency-bound levels: up to 9 of them per launch, children in LDS
+        typedef msmerkle::InnerSubtreeKernel SK;
+        u32 nl = 0; for (size_t m = nchildren; m > 1 && nl < (u32)SK::MAX_LEVELS; m >>= 1) nl++;
+        const size_t left = nchildren >> nl;
+        if (final_levels && left == 1) {
+          ip.host_root = host_root(); root_on_host = true;
+          if (pending_aux) { ip.aux_src = pending_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
+        }
+        ip.nlevels = nl;
+        next_bytes = (double)nchildren * 32 * 2;
+        CK(run_coop<SK>(K_INNER_HASH, (unsigned)left, SK::THREADS, SK::lds_bytes(), ip));
+        for (u32 l = 0; l < nl; l++) { child_off += nchildren; nchildren >>= 1; }
+        continue;
+      }
       if (final_levels && (nparents == 1 || nparents <= (size_t)tree_top_parents)) {
         ip.host_root = host_root(); root_on_host = true;
         if (pending_aux) { ip.aux_src = pending_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
@@ -961,6 +979,8 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_LDE_MULTI")) lde_multi = atoi(e);
     if (const char* e = getenv("MS_LDE_VIRTUAL")) lde_virtual = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
+    if (const char* e = getenv("MS_FOLD_SMALL_MAX")) fold_small_max = (size_t)atol(e);
+    if (const char* e = getenv("MS_TREE_SUBTREE_PARENTS")) subtree_parents = (size_t)atol(e);
     // the boundary's bulk copies (r04): page-locked trace in / FRI proof out on SDMA engines through the HSA runtime by default (measured with 8 provers in flight,
     // tools/io_probe3.py: resident 251 proofs/s; upload by hipMemcpyAsync 238, by SDMA 251; read-back by hipMemcpyAsync 217-223, by SDMA 242-248; both by SDMA 245.5 = 0.978)
     if (const char* e = getenv("MS_UPLOAD")) upload_sdma = !strcmp(e, "hip") ? 0 : 1;
@@ -1576,7 +1596,15 @@ template <class F> struct Ctx : CtxBase {
         const size_t total = m_out * fp.groups;
         next_bytes = (double)total * E * sizeof(T) * 3;   // two inputs read, one output written per element
         if (shard_next) part_depth++;
-        const int e_ = run<FK>(K_FOLD, grid1(total, FK::THREADS * FK::ITEMS), 1, FK::THREADS, 0, fp);
+        typedef mspoly::FriFoldEvalKernel<F, E, 1> FK1;     // one output per thread: the late rounds' launches are latency, not throughput (MS_FOLD_SMALL_MAX outputs at most)
+        int e_;
+        if (total <= fold_small_max) {
+          typename FK1::Params f1;
+          static_assert(sizeof(f1) == sizeof(fp), "same parameter block");
+          memcpy(&f1, &fp, sizeof fp);
+          e_ = run<FK1>(K_FOLD, grid1(total, FK1::THREADS), 1, FK1::THREADS, 0, f1);
+        } else
+        e_ = run<FK>(K_FOLD, grid1(total, FK::THREADS * FK::ITEMS), 1, FK::THREADS, 0, fp);
         if (shard_next) part_depth--;
         CK(e_);
         if (shard_next) RQ((tree_build_sharded<E>(r->cw.template as<T>(), m_out, 1, 2 * m_out, 2, r->ts, r->nodes)));

@@ -468,12 +468,15 @@ template <class F, int E> struct SuffixHornerKernel {
 // r = i (replicated round) or 2*(rank + W*i) + t (sharded round: this rank's two cosets).
 template <class F> MS_HD typename F::T fold_base_inv(typename F::T x) { return f_inv<F>(x); }
 template <> MS_HD u64 fold_base_inv<GL>(u64 x) { return gl_inv_chain(x); }
-template <class F, int E> struct FriFoldEvalKernel {
+// ITEMS_: outputs per thread.  8 amortises the field inversion over eight norms (the throughput choice); 1 is the LATENCY choice for the small late rounds, where a
+// launch is one wave deep anyway and eight serial outputs per thread only stretch it (with 8 a launch took 22 us whatever its size; one proof alone on the GPU:
+// 118.6 -> 120.4 proofs/s, eight in flight: neutral - profiles/r04_small_round_kernels_ab.log).
+template <class F, int E, int ITEMS_ = 8> struct FriFoldEvalKernel {
   typedef typename F::T T;
   typedef Ext<F, E> X;
   static_assert(E == 2 || E == 4, "quadratic or quartic tower");
   static constexpr int THREADS = mspoly::THREADS;
-  static constexpr int ITEMS = 8;
+  static constexpr int ITEMS = ITEMS_;
   struct Params {
     const T* src; size_t src_limb_stride; T* dst; size_t dst_limb_stride;
     size_t m_out; u32 log_m /* log2 m_out */, groups, shard_W, shard_k;

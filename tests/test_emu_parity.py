@@ -241,6 +241,24 @@ def test_virtual_linear_lde_columns(mk, monkeypatch, field, virtual):
     pc.case_prove(fresh, field, 6, 4, read_big=False)
 
 
+@pytest.mark.parametrize("field,parents", [(0, "0"), (1, "0"), (0, "4"), (0, "4096"), (1, "1048576")])
+def test_tree_levels_as_subtree_launches_or_one_by_one(mk, monkeypatch, field, parents):
+    """r04: binary-tree levels of at most MS_TREE_SUBTREE_PARENTS parents (default 65536) run nine to a launch with the children in LDS (InnerSubtreeKernel);
+    0: one launch per level and the fused top (the r01-r03 path, still what non-binary trees use).  Same roots, paths and proofs either way."""
+    monkeypatch.setenv("MS_TREE_SUBTREE_PARENTS", parents)
+    fresh = lambda f, fresh=False: mk(f, fresh=True)
+    pc.case_prove(fresh, field, 9, 8, read_big=False)
+    pc.case_prove(fresh, field, 3, 2, read_big=False)
+
+
+@pytest.mark.parametrize("field,small_max", [(0, "0"), (1, "0"), (0, "1000000000"), (1, "1000000000")])
+def test_fold_kernel_choice_by_round_size(mk, monkeypatch, field, small_max):
+    """r04: rounds of at most MS_FOLD_SMALL_MAX outputs (default 16384) fold with one output per thread (latency), longer ones with eight (the inversion shared by
+    eight norms): the same proof with every round forced through either kernel."""
+    monkeypatch.setenv("MS_FOLD_SMALL_MAX", small_max)
+    pc.case_prove(lambda f, fresh=False: mk(f, fresh=True), field, 8, 8, read_big=False)
+
+
 @pytest.mark.parametrize("field,log_n,w", [(0, 4, 4), (1, 4, 4), (0, 5, 6), (1, 3, 5)])
 def test_mix_cubic_true_quotient(mk, field, log_n, w):
     """BASELINE configs[4] "degree-3 constraints" (build-defined; VERDICT r2 missing #6): ms_mix_cubic against the big-integer definition, the DEEP-ALI
