@@ -561,7 +561,7 @@ def main():
             peak_guide = N_SIMD * CLOCK_HZ / 2.0      # SIMD-32: a wave64 VALU instruction occupies the SIMD for 2 cycles
             peak_meas = N_SIMD * CLOCK_HZ / 3.4       # measured: 3.3-3.6 cycles per VALU instruction in register-resident integer code (tools/ntt_lab.hip, r02)
             rv = {}
-            for cls, prefixes in (("leaf_hash", ("msmerkle::LeafHashKernel", "msmerkle::PadOnlyBlockKernel")), ("inner_hash", ("msmerkle::InnerHashKernelT",))):
+            for cls, prefixes in (("leaf_hash", ("msmerkle::LeafHashKernel", "msmerkle::PadOnlyBlockKernel")), ("inner_hash", ("msmerkle::InnerHashKernelT", "msmerkle::InnerSubtreeKernel"))):
                 wi = wave_instr(prefixes)
                 ms_cls = prof[cls]["ms"]
                 if wi and ms_cls:

@@ -1577,34 +1577,30 @@ template <class F> struct Ctx : CtxBase {
       if (prev && fri_pointwise && z_outside_base && prev->D == 2 * r->D && prev->ts.sharded == shard_next) {
         Plan* pl;
         RQ(get_plan(ctz64(prev->D), 0, false, &pl));   // w_D^e tables of the previous domain
-        typedef mspoly::FriFoldEvalKernel<F, E> FK;
-        typename FK::Params fp;
+        // one output per thread in the late rounds (at most MS_FOLD_SMALL_MAX outputs: their launches are latency, not throughput), eight otherwise
         const size_t W = (size_t)sh_world;
         const size_t m_out = shard_next ? r->D / (2 * W) : r->D;
         const size_t local = shard_next ? 2 * m_out : r->D;       // elements per limb held here
         if (shard_next) r->m = m_out;
         if (r->cw.ensure(local * E * sizeof(T))) return fail(MS_ERR_NOMEM, "codeword");
-        fp.src = prev->cw.template as<T>(); fp.src_limb_stride = shard_next ? 2 * prev->m : prev->D;
-        fp.dst = r->cw.template as<T>(); fp.dst_limb_stride = local;
-        fp.m_out = m_out; fp.log_m = (u32)ctz64(m_out); fp.groups = shard_next ? 2 : 1; fp.shard_W = shard_next ? (u32)W : 0; fp.shard_k = (u32)sh_rank;
-        fp.tw_lo = pl->tw_lo.template as<T>(); fp.tw_hi = pl->tw_hi.template as<T>(); fp.lo_bits = (u32)pl->lo_bits; fp.log_D = (u32)ctz64(prev->D);
-        fp.alpha = *alpha;
+        const size_t total = m_out * (shard_next ? 2 : 1);
         const XE c = e_add<F, E>(cur_B[0], e_mul<F>(cur_B[1], *alpha));   // B(alpha), fri.rs:99
-        fp.c2 = e_add<F, E>(c, c);
-        fp.z = cur_z;
-        fp.inv2 = f_inv<F>(F::from_u64(2));
-        const size_t total = m_out * fp.groups;
+        auto fold_launch = [&](auto* kernel) {
+          typedef typename std::remove_pointer<decltype(kernel)>::type FK;
+          typename FK::Params fp;
+          fp.src = prev->cw.template as<T>(); fp.src_limb_stride = shard_next ? 2 * prev->m : prev->D;
+          fp.dst = r->cw.template as<T>(); fp.dst_limb_stride = local;
+          fp.m_out = m_out; fp.log_m = (u32)ctz64(m_out); fp.groups = shard_next ? 2 : 1; fp.shard_W = shard_next ? (u32)W : 0; fp.shard_k = (u32)sh_rank;
+          fp.tw_lo = pl->tw_lo.template as<T>(); fp.tw_hi = pl->tw_hi.template as<T>(); fp.lo_bits = (u32)pl->lo_bits; fp.log_D = (u32)ctz64(prev->D);
+          fp.alpha = *alpha;
+          fp.c2 = e_add<F, E>(c, c);
+          fp.z = cur_z;
+          fp.inv2 = f_inv<F>(F::from_u64(2));
+          return run<FK>(K_FOLD, grid1(total, FK::THREADS * FK::ITEMS), 1, FK::THREADS, 0, fp);
+        };
         next_bytes = (double)total * E * sizeof(T) * 3;   // two inputs read, one output written per element
         if (shard_next) part_depth++;
-        typedef mspoly::FriFoldEvalKernel<F, E, 1> FK1;     // one output per thread: the late rounds' launches are latency, not throughput (MS_FOLD_SMALL_MAX outputs at most)
-        int e_;
-        if (total <= fold_small_max) {
-          typename FK1::Params f1;
-          static_assert(sizeof(f1) == sizeof(fp), "same parameter block");
-          memcpy(&f1, &fp, sizeof fp);
-          e_ = run<FK1>(K_FOLD, grid1(total, FK1::THREADS), 1, FK1::THREADS, 0, f1);
-        } else
-        e_ = run<FK>(K_FOLD, grid1(total, FK::THREADS * FK::ITEMS), 1, FK::THREADS, 0, fp);
+        const int e_ = total <= fold_small_max ? fold_launch((mspoly::FriFoldEvalKernel<F, E, 1>*)nullptr) : fold_launch((mspoly::FriFoldEvalKernel<F, E, 8>*)nullptr);
         if (shard_next) part_depth--;
         CK(e_);
         if (shard_next) RQ((tree_build_sharded<E>(r->cw.template as<T>(), m_out, 1, 2 * m_out, 2, r->ts, r->nodes)));
