@@ -118,7 +118,8 @@ template <class F> struct Ctx : CtxBase {
                        // per Fibonacci proof alone, but 248 -> 240 proofs/s with 8 proofs in flight (five interleaved runs each)
   int tree_top_parents = msmerkle::THREADS;  // MS_TREE_TOP: levels of at most this many parents are walked by one workgroup in one launch (measured: 256 beats 1024 by 3 % in latency)
   int leaf_lazy_min = 16;  // MS_LEAF_LAZY_MIN: leaf groups of at least this many base limbs use the wave-synchronous two-block leaf kernel
-  size_t fold_small_max = 16384;   // MS_FOLD_SMALL_MAX
+  size_t fold_small_max = 131072;  // MS_FOLD_SMALL_MAX (16384 / 131072 / 2^20: within noise of each other with one proof and with eight in flight; 0 is 1.5 % slower with one)
+  size_t eval_small_max = (size_t)1 << 19;   // MS_EVAL_SMALL_MAX: polynomials of at most this many coefficients are evaluated 4 coefficients per thread (latency), longer ones 16
   // MS_TREE_SUBTREE_PARENTS: binary-tree levels of at most this many parents run as subtree launches (msmerkle::InnerSubtreeKernel); 0: one launch per level + the fused top.
   // Same-box A/B, 8 proofs in flight: 4096 -> +0.8 % over 0, 65536 -> -0.8 %; one proof in flight: +1.6 % with 65536 (profiles/r04_small_round_kernels_ab.log)
   size_t subtree_parents = 4096;
@@ -980,6 +981,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_LDE_VIRTUAL")) lde_virtual = atoi(e);
     if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
     if (const char* e = getenv("MS_FOLD_SMALL_MAX")) fold_small_max = (size_t)atol(e);
+    if (const char* e = getenv("MS_EVAL_SMALL_MAX")) eval_small_max = (size_t)atol(e);
     if (const char* e = getenv("MS_TREE_SUBTREE_PARENTS")) subtree_parents = (size_t)atol(e);
     // the boundary's bulk copies (r04): page-locked trace in / FRI proof out on SDMA engines through the HSA runtime by default (measured with 8 provers in flight,
     // tools/io_probe3.py: resident 251 proofs/s; upload by hipMemcpyAsync 238, by SDMA 251; read-back by hipMemcpyAsync 217-223, by SDMA 242-248; both by SDMA 245.5 = 0.978)
@@ -1446,7 +1448,12 @@ template <class F> struct Ctx : CtxBase {
   int eval_views(const T* base, size_t poly_stride, size_t limb_stride, size_t kstride, const size_t* off, const size_t* count, int npoly, const XE& z, T* dst) {
     size_t maxc = 0;
     for (int i = 0; i < npoly; i++) if (count[i] > maxc) maxc = count[i];
-    typedef mspoly::EvalKernel<F, EC, E> EK;
+    return maxc <= eval_small_max ? eval_views_i<EC, 4>(base, poly_stride, limb_stride, kstride, off, count, npoly, z, dst, maxc)
+                                  : eval_views_i<EC, 16>(base, poly_stride, limb_stride, kstride, off, count, npoly, z, dst, maxc);
+  }
+  template <int EC, int ITEMS>
+  int eval_views_i(const T* base, size_t poly_stride, size_t limb_stride, size_t kstride, const size_t* off, const size_t* count, int npoly, const XE& z, T* dst, size_t maxc) {
+    typedef mspoly::EvalKernel<F, EC, E, ITEMS> EK;
     const size_t chunk = (size_t)EK::THREADS * EK::ITEMS;
     const size_t nblocks = maxc ? (maxc + chunk - 1) / chunk : 1;
     if (nblocks > 1 && d_partials.ensure(nblocks * npoly * E * sizeof(T))) return fail(MS_ERR_NOMEM, "partials");

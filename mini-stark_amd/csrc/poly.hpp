@@ -186,17 +186,20 @@ template <class F> struct MixKernel {
 // P_b (WITHOUT the factor z^(b*CH)).  ReducePartials then forms sum_b P_b (z^CH)^b.
 // With a single block the result goes straight to `dst`.
 constexpr int MAX_POLYS = 8;
-template <class F, int EC, int E> struct EvalKernel {
+// ITEMS_ = coefficients per thread: 16 for long polynomials, 4 up to 2^19 coefficients (MS_EVAL_SMALL_MAX), whose launches are latency - 16 dependent
+// load + multiply-add iterations per thread made a 2^15-coefficient evaluation as slow as a 2^19-coefficient one, 28-34 us; with 4: 12-18 us, the Eval launches of
+// one proof 400 -> 260 us, ReducePartials 62 -> 77 us; eight proofs in flight: neutral (profiles/r04_small_round_kernels_ab.log).
+template <class F, int EC, int E, int ITEMS_ = 16> struct EvalKernel {
   typedef typename F::T T;
   static constexpr int THREADS = mspoly::THREADS;
-  static constexpr int ITEMS = 16;
+  static constexpr int ITEMS = ITEMS_;
   struct Params {
     const T* base; size_t poly_stride, limb_stride, kstride;
     size_t off[MAX_POLYS], count[MAX_POLYS]; int npoly;
     Ext<F, E> zpow2[9];   // z^(2^i), i <= 8  (zpow2[8] = z^THREADS)
     T* partials;          // [nblocks][npoly][E]
   };
-  static MS_HD size_t lds_bytes() { return (size_t)MAX_POLYS * E * (THREADS / 64) * sizeof(T); }
+  static MS_HD size_t lds_bytes() { return ((size_t)MAX_POLYS * E * (THREADS / 64) + 32 * (size_t)E) * sizeof(T); }
   static MS_DEV Ext<F, E> mul_coef(const Ext<F, E>& pw, const T* c) {
     if (EC == 1) return e_mul_base<F, E>(pw, c[0]);
     Ext<F, E> cc; for (int l = 0; l < E; l++) cc.c[l] = c[l < EC ? l : 0];
@@ -208,15 +211,26 @@ template <class F, int EC, int E> struct EvalKernel {
   static MS_DEV void run(const Params& p, int bx, int, int, int tid, unsigned char* lds) {
     T* red = reinterpret_cast<T*>(lds);  // [npoly*E][waves]
     constexpr int WAVES = THREADS / 64;
+    // z^tid = z^(tid & 15) * z^(16 (tid >> 4)): 32 lanes build the two 16-entry tables (4 multiplications each), every thread then needs ONE multiplication
+    // instead of the eight of a per-thread bit product (which were a third of a thread's multiplications with two polynomials and 16 coefficients each)
+    T* tab = red + (size_t)MAX_POLYS * E * WAVES;  // [32][E]
+    if (tid < 32) {
+      Ext<F, E> tw = e_one<F, E>();
+      const int j = tid & 15, b0 = tid & 16 ? 4 : 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) if ((j >> i) & 1) tw = e_mul<F>(tw, p.zpow2[b0 + i]);
+      for (int l = 0; l < E; l++) tab[(size_t)tid * E + l] = tw.c[l];
+    }
+    msrt::wg_barrier();
     Ext<F, E> acc[MAX_POLYS];
     for (int i = 0; i < MAX_POLYS; i++) acc[i] = e_zero<F, E>();
     size_t k = (size_t)bx * (THREADS * ITEMS) + tid;
     size_t kmax = 0;
     for (int i = 0; i < MAX_POLYS; i++) if (i < p.npoly && p.count[i] > kmax) kmax = p.count[i];
     if (k < kmax) {
-      Ext<F, E> pw = e_one<F, E>();
-#pragma unroll
-      for (int i = 0; i < 8; i++) if ((tid >> i) & 1) pw = e_mul<F>(pw, p.zpow2[i]);
+      Ext<F, E> plo, phi;
+      for (int l = 0; l < E; l++) { plo.c[l] = tab[(size_t)(tid & 15) * E + l]; phi.c[l] = tab[(size_t)(16 + (tid >> 4)) * E + l]; }
+      Ext<F, E> pw = e_mul<F>(plo, phi);
       const Ext<F, E> zstep = p.zpow2[8];
       for (int it = 0; it < ITEMS && k < kmax; it++, k += THREADS) {
 #pragma unroll

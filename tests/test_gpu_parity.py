@@ -492,8 +492,16 @@ def test_tree_levels_as_subtree_launches_or_one_by_one(mk, monkeypatch, field, p
 
 
 @pytest.mark.parametrize("field,small_max", [(0, "0"), (1, "0"), (0, "1000000000"), (1, "1000000000")])
+def test_eval_kernel_choice_by_polynomial_length(mk, monkeypatch, field, small_max):
+    """r04: polynomials of at most MS_EVAL_SMALL_MAX coefficients (default 2^19) are evaluated with 4 coefficients per thread, longer ones with 16: the DEEP-ALI
+    values and every FRI round's B with either kernel forced."""
+    monkeypatch.setenv("MS_EVAL_SMALL_MAX", small_max)
+    pc.case_prove(lambda f, fresh=False: mk(f, fresh=True), field, 13, 8, read_big=False)
+
+
+@pytest.mark.parametrize("field,small_max", [(0, "0"), (1, "0"), (0, "1000000000"), (1, "1000000000")])
 def test_fold_kernel_choice_by_round_size(mk, monkeypatch, field, small_max):
-    """r04: rounds of at most MS_FOLD_SMALL_MAX outputs (default 16384) fold with one output per thread (latency), longer ones with eight (the inversion shared by
+    """r04: rounds of at most MS_FOLD_SMALL_MAX outputs (default 131072) fold with one output per thread (latency), longer ones with eight (the inversion shared by
     eight norms): the same proof with every round forced through either kernel."""
     monkeypatch.setenv("MS_FOLD_SMALL_MAX", small_max)
     pc.case_prove(lambda f, fresh=False: mk(f, fresh=True), field, 12, 8, read_big=False)
