@@ -327,13 +327,13 @@ template <class F> struct Ctx : CtxBase {
   }
   static const char* fname() { return F::ID == 0 ? "GL" : "BB"; }
   template <class A> static const char* aname() { return std::is_same<A, GLM>::value ? "GLM" : (std::is_same<A, GLT>::value ? "GLT" : (std::is_same<A, GL>::value ? "GL" : "BB")); }
-  template <class K> int run_coop(int kid, unsigned gx, int threads, size_t lds, const typename K::Params& p) {
-    if (gx == 0) return 0;
-    if (!prof_on) return msrt::launch_coop<K>(stream, gx, 1, threads, lds, p);
+  template <class K> int run_coop(int kid, unsigned gx, int threads, size_t lds, const typename K::Params& p, unsigned gy = 1) {
+    if (gx == 0 || gy == 0) return 0;
+    if (!prof_on) return msrt::launch_coop<K>(stream, gx, gy, threads, lds, p);
     ProfRec r; r.kid = kid; r.sub = next_sub; r.bytes = next_bytes; r.part = part_depth > 0; next_bytes = 0; next_sub = 0;
     if (msrt::event_create(&r.a) || msrt::event_create(&r.b)) return 1;
     msrt::event_record(r.a, stream);
-    int e = msrt::launch_coop<K>(stream, gx, 1, threads, lds, p);
+    int e = msrt::launch_coop<K>(stream, gx, gy, threads, lds, p);
     msrt::event_record(r.b, stream);
     prof_recs.push_back(r);
     return e;
@@ -1768,7 +1768,7 @@ template <class F> struct Ctx : CtxBase {
   int sh_launch_inline(const SHJ& j, int final_mode) {
     typename SHK::Params p; p.jobs = nullptr; p.inline_job = j; p.final_mode = final_mode;
     const size_t nb = j.m ? (j.m + mspoly::SH_BS - 1) / mspoly::SH_BS : 1;
-    CK(run<SHK>(K_SUFFIX_HORNER, (unsigned)nb, 1, SHK::THREADS, SHK::lds_bytes(), p));
+    CK(run_coop<SHK>(K_SUFFIX_HORNER, (unsigned)nb, SHK::THREADS, SHK::lds_bytes(), p));
     return 0;
   }
   // one logical job, launched level by level with the job inline in the kernel arguments
@@ -2142,7 +2142,7 @@ template <class F> struct Ctx : CtxBase {
       typename SHK::Params p; p.jobs = reinterpret_cast<const SHJ*>(dt + toff[k]); p.final_mode = table_mode[k];
       memset(&p.inline_job, 0, sizeof p.inline_job);
       if (table_part[k]) part_depth++;
-      const int e_ = run<SHK>(K_SUFFIX_HORNER, (unsigned)maxnb, (unsigned)tables[k].size(), SHK::THREADS, SHK::lds_bytes(), p);
+      const int e_ = run_coop<SHK>(K_SUFFIX_HORNER, (unsigned)maxnb, SHK::THREADS, SHK::lds_bytes(), p, (unsigned)tables[k].size());
       if (table_part[k]) part_depth--;
       CK(e_);
     }
@@ -2191,7 +2191,7 @@ template <class F> struct Ctx : CtxBase {
       }
       if (!pjobs.empty()) {
         typename msmerkle::PathKernel<F, E>::Params pk{reinterpret_cast<const PJ*>(dt + off_p), (u32)pjobs.size()};
-        CK(run<msmerkle::PathKernel<F, E>>(K_PATH, grid1(pjobs.size(), 64), 1, 64, 0, pk));
+        CK(run<msmerkle::PathKernel<F, E>>(K_PATH, (unsigned)pjobs.size(), 1, 64, 0, pk));   // one wave per opening
       }
       if (!sjobs.empty()) {
         typename msmerkle::ShardPathKernel<F, E>::Params sk{reinterpret_cast<const SPJ*>(dt + off_sp), (u32)sjobs.size()};

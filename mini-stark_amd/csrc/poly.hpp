@@ -371,27 +371,29 @@ template <class F, int E> struct SuffixHornerKernel {
   typedef SHJob<F, E> Job;
   static constexpr int THREADS = mspoly::THREADS;
   struct Params { const Job* jobs; Job inline_job; int final_mode; };
-  static MS_HD int nphases(const Params&) { return 2 + 9 + 2; }
   static MS_HD size_t lds_bytes() { return ((size_t)E * SH_BS + 2 * (size_t)E * (THREADS + 1)) * sizeof(T); }
-  static MS_DEV void phase(int ph, const Params& p, int bx, int by, int tid, int nthreads, unsigned char* lds) {
-    const Job& jb = p.jobs ? p.jobs[by] : p.inline_job;
+  // Cooperative kernel (r04; thirteen barrier-separated phases of the generic phase harness until then): the job is read ONCE - as phases, every step fetched its
+  // fields from the job table again behind a barrier that also drains vector memory, and a launch cost 17-19 us whatever its size; these launches sit on the proof's
+  // latency path (one to three per FRI round).
+  static MS_DEV void run(const Params& p, int bx, int by, int, int tid, unsigned char* lds) {
+    const Job jb = p.jobs ? p.jobs[by] : p.inline_job;
     const size_t nb = jb.m ? (jb.m + SH_BS - 1) / SH_BS : 1;
-    if ((size_t)bx >= nb) return;
+    if ((size_t)bx >= nb) return;   // (the whole workgroup)
     T* fbuf = reinterpret_cast<T*>(lds);                 // [E][BS]
     T* sa = fbuf + (size_t)E * SH_BS;                    // [E][THREADS+1]  ping
     T* sb = sa + (size_t)E * (THREADS + 1);              // pong
     const size_t j0 = (size_t)bx * SH_BS;
-    if (ph == 0) {  // coalesced load
-      for (int i = tid; i < SH_BS; i += nthreads) {
-        const size_t j = j0 + i;
-        for (int l = 0; l < E; l++)
-          fbuf[(size_t)l * SH_BS + i] = (j < jb.m) ? jb.in[(size_t)l * jb.in_limb_stride + jb.in_off + j * jb.in_stride] : (T)0;
-      }
-      return;
+    // coalesced load
+    for (int i = tid; i < SH_BS; i += THREADS) {
+      const size_t j = j0 + i;
+      for (int l = 0; l < E; l++)
+        fbuf[(size_t)l * SH_BS + i] = (j < jb.m) ? jb.in[(size_t)l * jb.in_limb_stride + jb.in_off + j * jb.in_stride] : (T)0;
     }
-    if (ph == 1) {  // per-thread segment aggregate a_t
-      const Ext<F, E> z = jb.z;
+    msrt::wg_barrier();
+    const Ext<F, E> z = jb.z;
+    {  // per-thread segment aggregate a_t
       Ext<F, E> a = e_zero<F, E>();
+#pragma unroll
       for (int i = SH_SEG - 1; i >= 0; i--) {
         Ext<F, E> c; for (int l = 0; l < E; l++) c.c[l] = fbuf[(size_t)l * SH_BS + tid * SH_SEG + i];
         a = e_add<F, E>(e_mul<F>(a, z), c);
@@ -404,14 +406,15 @@ template <class F, int E> struct SuffixHornerKernel {
           sa[(size_t)l * (THREADS + 1) + THREADS] = cv;
         }
       }
-      return;
     }
-    if (ph < 2 + 9) {  // suffix scan over THREADS+1 entries, distance d = 2^(ph-2)
-      const int step = ph - 2, d = 1 << step;
+    msrt::wg_barrier();
+#pragma unroll
+    for (int step = 0; step < 9; step++) {  // suffix scan over THREADS+1 entries, distance d = 2^step
+      const int d = 1 << step;
       T* src = (step & 1) ? sb : sa;
       T* dst = (step & 1) ? sa : sb;
       const Ext<F, E> zp = jb.zpow[step];
-      for (int t = tid; t <= THREADS; t += nthreads) {
+      for (int t = tid; t <= THREADS; t += THREADS) {
         Ext<F, E> v; for (int l = 0; l < E; l++) v.c[l] = src[(size_t)l * (THREADS + 1) + t];
         if (t + d <= THREADS) {
           Ext<F, E> u; for (int l = 0; l < E; l++) u.c[l] = src[(size_t)l * (THREADS + 1) + t + d];
@@ -419,25 +422,24 @@ template <class F, int E> struct SuffixHornerKernel {
         }
         for (int l = 0; l < E; l++) dst[(size_t)l * (THREADS + 1) + t] = v.c[l];
       }
-      return;
+      msrt::wg_barrier();
     }
     T* sc = sb;  // 9 steps: the last one (step 8, even) wrote sb
-    if (ph == 2 + 9) {
-      if (!p.final_mode) {
-        if (tid == 0) for (int l = 0; l < E; l++) jb.agg[(size_t)l * jb.agg_limb_stride + bx] = sc[(size_t)l * (THREADS + 1)];
-        return;
-      }
-      const Ext<F, E> z = jb.z;
+    if (!p.final_mode) {
+      if (tid == 0) for (int l = 0; l < E; l++) jb.agg[(size_t)l * jb.agg_limb_stride + bx] = sc[(size_t)l * (THREADS + 1)];
+      return;
+    }
+    {
       Ext<F, E> h; for (int l = 0; l < E; l++) h.c[l] = sc[(size_t)l * (THREADS + 1) + tid + 1];
+#pragma unroll
       for (int i = SH_SEG - 1; i >= 0; i--) {
         Ext<F, E> c; for (int l = 0; l < E; l++) c.c[l] = fbuf[(size_t)l * SH_BS + tid * SH_SEG + i];
         h = e_add<F, E>(e_mul<F>(h, z), c);
         for (int l = 0; l < E; l++) fbuf[(size_t)l * SH_BS + tid * SH_SEG + i] = h.c[l];
       }
-      return;
     }
-    if (!p.final_mode) return;
-    for (int i = tid; i < SH_BS; i += nthreads) {
+    msrt::wg_barrier();
+    for (int i = tid; i < SH_BS; i += THREADS) {
       const size_t j = j0 + i;
       if (j >= jb.m && !(j == 0)) continue;
       for (int l = 0; l < E; l++) {
