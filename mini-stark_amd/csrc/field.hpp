@@ -64,6 +64,7 @@ struct GL {
   static MS_HD u64 to_u64(T v) { return v; }
   // twiddle tables hold to_tw(w); mul_tw(a, to_tw(w)) == a * w.  Nothing to gain for Goldilocks: identity.
   static MS_HD T to_tw(T w) { return w; }
+  static MS_HD T tw_of(T w) { return w; }
   static MS_HD T mul_tw(T a, T w_tab) { return mul(a, w_tab); }
   static MS_HD T from_tw(T w_tab) { return w_tab; }
 };
@@ -270,6 +271,7 @@ struct BB {
   // twiddle tables hold the Montgomery form w * 2^32 mod p: a canonical value times a table entry is ONE product and ONE
   // reduction (a * wR / R = a * w), and the product of two table entries is again in table form
   static MS_HD T to_tw(T w) { return (T)((((u64)w) << 32) % P); }
+  static MS_HD T tw_of(T w) { return redc((u64)w * (u64)R2); }   // == to_tw(w) without the 64-bit modulo (device code: run-time values)
   static MS_HD T mul_tw(T a, T w_tab) { return redc((u64)a * (u64)w_tab); }
   static MS_HD T from_tw(T w_tab) { return redc((u64)w_tab); }
 };
@@ -323,23 +325,45 @@ template <class F> MS_HD Ext<F, 2> e_mul(const Ext<F, 2>& a, const Ext<F, 2>& b)
   typename F::T v1 = F::mul(a.c[1], b.c[1]);
   typename F::T s = F::mul(F::add(a.c[0], a.c[1]), F::add(b.c[0], b.c[1]));
   Ext<F, 2> r;
-  r.c[0] = F::add(v0, F::mul(F::from_u64(F::NR2), v1));
+  r.c[0] = F::add(v0, F::mul_tw(v1, F::to_tw(F::from_u64(F::NR2))));   // the constant in table form (folded at compile time): one product + one reduction for BabyBear
   r.c[1] = F::sub(F::sub(s, v0), v1);
   return r;
 }
 // multiply an Fp2 element by the quartic non-residue (2013265910 + u) = (u - 11) (BabyBear)
 template <class F> MS_HD Ext<F, 2> e_mul_nr4(const Ext<F, 2>& a) {
   // (a0 + a1 u)(n0 + u) = (a0 n0 + NR2 a1) + (a0 + a1 n0) u ,  n0 = 2013265910 = -11 mod p
-  typename F::T n0 = F::from_u64(2013265910ULL % F::P);
+  const typename F::T n0 = F::to_tw(F::from_u64(2013265910ULL % F::P)), nr = F::to_tw(F::from_u64(F::NR2));   // table form, compile-time constants
   Ext<F, 2> r;
-  r.c[0] = F::add(F::mul(a.c[0], n0), F::mul(F::from_u64(F::NR2), a.c[1]));
-  r.c[1] = F::add(a.c[0], F::mul(a.c[1], n0));
+  r.c[0] = F::add(F::mul_tw(a.c[0], n0), F::mul_tw(a.c[1], nr));
+  r.c[1] = F::add(a.c[0], F::mul_tw(a.c[1], n0));
   return r;
 }
 template <class F> MS_HD Ext<F, 4> e_mul(const Ext<F, 4>& a, const Ext<F, 4>& b) {
   Ext<F, 2> a0{{a.c[0], a.c[1]}}, a1{{a.c[2], a.c[3]}}, b0{{b.c[0], b.c[1]}}, b1{{b.c[2], b.c[3]}};
   Ext<F, 2> v0 = e_mul<F>(a0, b0), v1 = e_mul<F>(a1, b1);
   Ext<F, 2> s = e_mul<F>(e_add<F, 2>(a0, a1), e_add<F, 2>(b0, b1));
+  Ext<F, 2> r0 = e_add<F, 2>(v0, e_mul_nr4<F>(v1));
+  Ext<F, 2> r1 = e_sub<F, 2>(e_sub<F, 2>(s, v0), v1);
+  Ext<F, 4> r; r.c[0] = r0.c[0]; r.c[1] = r0.c[1]; r.c[2] = r1.c[0]; r.c[3] = r1.c[1];
+  return r;
+}
+// a * b with b's limbs in TABLE form (e_to_tw): every base product is F::mul_tw - one product and one reduction for BabyBear instead of two (Goldilocks: the same
+// code as e_mul).  Linear in a, so a in table form gives the product in table form.  For loop-invariant multiplicands (the point of a Horner scan, the step of a power).
+template <class F, int E> MS_HD Ext<F, E> e_to_tw(const Ext<F, E>& b) { Ext<F, E> r; for (int i = 0; i < E; i++) r.c[i] = F::tw_of(b.c[i]); return r; }
+template <class F> MS_HD Ext<F, 1> e_mul_tw(const Ext<F, 1>& a, const Ext<F, 1>& bt) { Ext<F, 1> r; r.c[0] = F::mul_tw(a.c[0], bt.c[0]); return r; }
+template <class F> MS_HD Ext<F, 2> e_mul_tw(const Ext<F, 2>& a, const Ext<F, 2>& bt) {
+  typename F::T v0 = F::mul_tw(a.c[0], bt.c[0]);
+  typename F::T v1 = F::mul_tw(a.c[1], bt.c[1]);
+  typename F::T s = F::mul_tw(F::add(a.c[0], a.c[1]), F::add(bt.c[0], bt.c[1]));
+  Ext<F, 2> r;
+  r.c[0] = F::add(v0, F::mul_tw(v1, F::to_tw(F::from_u64(F::NR2))));
+  r.c[1] = F::sub(F::sub(s, v0), v1);
+  return r;
+}
+template <class F> MS_HD Ext<F, 4> e_mul_tw(const Ext<F, 4>& a, const Ext<F, 4>& bt) {
+  Ext<F, 2> a0{{a.c[0], a.c[1]}}, a1{{a.c[2], a.c[3]}}, b0{{bt.c[0], bt.c[1]}}, b1{{bt.c[2], bt.c[3]}};
+  Ext<F, 2> v0 = e_mul_tw<F>(a0, b0), v1 = e_mul_tw<F>(a1, b1);
+  Ext<F, 2> s = e_mul_tw<F>(e_add<F, 2>(a0, a1), e_add<F, 2>(b0, b1));
   Ext<F, 2> r0 = e_add<F, 2>(v0, e_mul_nr4<F>(v1));
   Ext<F, 2> r1 = e_sub<F, 2>(e_sub<F, 2>(s, v0), v1);
   Ext<F, 4> r; r.c[0] = r0.c[0]; r.c[1] = r0.c[1]; r.c[2] = r1.c[0]; r.c[3] = r1.c[1];

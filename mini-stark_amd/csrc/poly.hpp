@@ -200,10 +200,11 @@ template <class F, int EC, int E, int ITEMS_ = 16> struct EvalKernel {
     T* partials;          // [nblocks][npoly][E]
   };
   static MS_HD size_t lds_bytes() { return ((size_t)MAX_POLYS * E * (THREADS / 64) + 32 * (size_t)E) * sizeof(T); }
-  static MS_DEV Ext<F, E> mul_coef(const Ext<F, E>& pw, const T* c) {
-    if (EC == 1) return e_mul_base<F, E>(pw, c[0]);
+  // coefficient * power, the power in table form (e_to_tw)
+  static MS_DEV Ext<F, E> mul_coef(const Ext<F, E>& pwt, const T* c) {
+    if (EC == 1) { Ext<F, E> r; for (int l = 0; l < E; l++) r.c[l] = F::mul_tw(c[0], pwt.c[l]); return r; }
     Ext<F, E> cc; for (int l = 0; l < E; l++) cc.c[l] = c[l < EC ? l : 0];
-    return e_mul<F>(pw, cc);
+    return e_mul_tw<F>(cc, pwt);
   }
   // Cooperative kernel (barrier inside): the block sum runs as a butterfly of wave shuffles (6 steps) plus one LDS hop between the
   // four waves, instead of `width` threads each adding 256 LDS values one after the other (a ~3 us dependent chain per launch, and
@@ -230,8 +231,8 @@ template <class F, int EC, int E, int ITEMS_ = 16> struct EvalKernel {
     if (k < kmax) {
       Ext<F, E> plo, phi;
       for (int l = 0; l < E; l++) { plo.c[l] = tab[(size_t)(tid & 15) * E + l]; phi.c[l] = tab[(size_t)(16 + (tid >> 4)) * E + l]; }
-      Ext<F, E> pw = e_mul<F>(plo, phi);
-      const Ext<F, E> zstep = p.zpow2[8];
+      const Ext<F, E> zstep = e_to_tw<F, E>(p.zpow2[8]);
+      Ext<F, E> pw = e_to_tw<F, E>(e_mul<F>(plo, phi));   // z^k in table form from here on: every product below is one multiplication + one reduction per limb pair
       for (int it = 0; it < ITEMS && k < kmax; it++, k += THREADS) {
 #pragma unroll
         for (int i = 0; i < MAX_POLYS; i++) {
@@ -242,7 +243,7 @@ template <class F, int EC, int E, int ITEMS_ = 16> struct EvalKernel {
             acc[i] = e_add<F, E>(acc[i], mul_coef(pw, c));
           }
         }
-        pw = e_mul<F>(pw, zstep);
+        pw = e_mul_tw<F>(pw, zstep);
       }
     }
     const int width = p.npoly * E;
@@ -390,13 +391,13 @@ template <class F, int E> struct SuffixHornerKernel {
         fbuf[(size_t)l * SH_BS + i] = (j < jb.m) ? jb.in[(size_t)l * jb.in_limb_stride + jb.in_off + j * jb.in_stride] : (T)0;
     }
     msrt::wg_barrier();
-    const Ext<F, E> z = jb.z;
+    const Ext<F, E> z = e_to_tw<F, E>(jb.z);   // table form: the multiplicand of every Horner step (e_mul_tw)
     {  // per-thread segment aggregate a_t
       Ext<F, E> a = e_zero<F, E>();
 #pragma unroll
       for (int i = SH_SEG - 1; i >= 0; i--) {
         Ext<F, E> c; for (int l = 0; l < E; l++) c.c[l] = fbuf[(size_t)l * SH_BS + tid * SH_SEG + i];
-        a = e_add<F, E>(e_mul<F>(a, z), c);
+        a = e_add<F, E>(e_mul_tw<F>(a, z), c);
       }
       for (int l = 0; l < E; l++) sa[(size_t)l * (THREADS + 1) + tid] = a.c[l];
       if (tid == 0) {  // virtual element THREADS = carry-in
@@ -413,12 +414,12 @@ template <class F, int E> struct SuffixHornerKernel {
       const int d = 1 << step;
       T* src = (step & 1) ? sb : sa;
       T* dst = (step & 1) ? sa : sb;
-      const Ext<F, E> zp = jb.zpow[step];
+      const Ext<F, E> zp = e_to_tw<F, E>(jb.zpow[step]);
       for (int t = tid; t <= THREADS; t += THREADS) {
         Ext<F, E> v; for (int l = 0; l < E; l++) v.c[l] = src[(size_t)l * (THREADS + 1) + t];
         if (t + d <= THREADS) {
           Ext<F, E> u; for (int l = 0; l < E; l++) u.c[l] = src[(size_t)l * (THREADS + 1) + t + d];
-          v = e_add<F, E>(v, e_mul<F>(u, zp));
+          v = e_add<F, E>(v, e_mul_tw<F>(u, zp));
         }
         for (int l = 0; l < E; l++) dst[(size_t)l * (THREADS + 1) + t] = v.c[l];
       }
@@ -434,7 +435,7 @@ template <class F, int E> struct SuffixHornerKernel {
 #pragma unroll
       for (int i = SH_SEG - 1; i >= 0; i--) {
         Ext<F, E> c; for (int l = 0; l < E; l++) c.c[l] = fbuf[(size_t)l * SH_BS + tid * SH_SEG + i];
-        h = e_add<F, E>(e_mul<F>(h, z), c);
+        h = e_add<F, E>(e_mul_tw<F>(h, z), c);
         for (int l = 0; l < E; l++) fbuf[(size_t)l * SH_BS + tid * SH_SEG + i] = h.c[l];
       }
     }
