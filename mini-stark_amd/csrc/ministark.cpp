@@ -121,8 +121,9 @@ template <class F> struct Ctx : CtxBase {
   size_t fold_small_max = 131072;  // MS_FOLD_SMALL_MAX (16384 / 131072 / 2^20: within noise of each other with one proof and with eight in flight; 0 is 1.5 % slower with one)
   size_t eval_small_max = (size_t)1 << 19;   // MS_EVAL_SMALL_MAX: polynomials of at most this many coefficients are evaluated 4 coefficients per thread (latency), longer ones 16
   // MS_TREE_SUBTREE_PARENTS: binary-tree levels of at most this many parents run as subtree launches (msmerkle::InnerSubtreeKernel); 0: one launch per level + the fused top.
-  // Same-box A/B, 8 proofs in flight: 4096 -> +0.8 % over 0, 65536 -> -0.8 %; one proof in flight: +1.6 % with 65536 (profiles/r04_small_round_kernels_ab.log)
-  size_t subtree_parents = 4096;
+  // Same-box A/Bs (profiles/r04_small_round_kernels_ab.log), final build, 4 passes: 8 proofs in flight 4096 / 16384 / 65536 -> 258.9 / 260.5 / 254.2 proofs/s, one proof in
+  // flight 127.0 / 129.6 / 130.3; against 0 (one launch per level): 4096 -> +0.8 % in flight, +1.2 % alone
+  size_t subtree_parents = 16384;
   int fri_pointwise = 1;  // MS_FRI_POINTWISE=0: codewords of FRI rounds >= 1 by NTT of the round polynomial instead of the evaluation-domain fold
   msrt::Stream* own_stream = nullptr;
   msrt::Stream* stream = nullptr;

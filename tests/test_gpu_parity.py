@@ -481,9 +481,9 @@ def test_virtual_linear_lde_columns(mk, monkeypatch, field, virtual):
     pc.case_prove(fresh, field, 6, 4, read_big=False)
 
 
-@pytest.mark.parametrize("field,parents", [(0, "0"), (1, "0"), (0, "4"), (0, "4096"), (1, "1048576")])
+@pytest.mark.parametrize("field,parents", [(0, "0"), (1, "0"), (0, "4"), (0, "4096"), (1, "1048576"), (0, "16384")])
 def test_tree_levels_as_subtree_launches_or_one_by_one(mk, monkeypatch, field, parents):
-    """r04: binary-tree levels of at most MS_TREE_SUBTREE_PARENTS parents (default 65536) run nine to a launch with the children in LDS (InnerSubtreeKernel);
+    """r04: binary-tree levels of at most MS_TREE_SUBTREE_PARENTS parents (default 16384) run nine to a launch with the children in LDS (InnerSubtreeKernel);
     0: one launch per level and the fused top (the r01-r03 path, still what non-binary trees use).  Same roots, paths and proofs either way."""
     monkeypatch.setenv("MS_TREE_SUBTREE_PARENTS", parents)
     fresh = lambda f, fresh=False: mk(f, fresh=True)
