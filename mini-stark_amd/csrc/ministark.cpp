@@ -138,6 +138,7 @@ template <class F> struct Ctx : CtxBase {
   ms_exchange_fn xfn = nullptr; void* xuser = nullptr;
   size_t shard_min_leaves = 32768;                        // MS_SHARD_MIN_LEAVES: smaller commitments stay replicated
   void* rccl_comm = nullptr; DevBuf rccl_send, rccl_recv;   // ms_set_shard_rccl: the library owns the communicator and the exchange buffers
+  size_t rccl_max_piece = (size_t)1 << 30;                  // MS_RCCL_MAX_PIECE: most bytes of one ncclSend / ncclRecv / ncclAllGather (see exchange)
   u64 xstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // calls per op [0..3], bytes sent per op [4..7] (ms_shard_stats)
   int exchange(int op, size_t bytes) {
     { const int slot = (op == MS_XCHG_GATHER) ? 1 : (op & 3);   // (the gather to rank 0 is counted with the all-gathers)
@@ -147,22 +148,39 @@ template <class F> struct Ctx : CtxBase {
       msrt::Rccl& R = msrt::Rccl::get();
       const int W = sh_world;
       int e = 0;
+      // One ncclSend / ncclRecv moves at most rccl_max_piece bytes (default 1 GiB; MS_RCCL_MAX_PIECE): found r05 by the full-size one-rank-world tests - RCCL 2.26.6
+      // delivers WRONG BYTES for a single send / recv of >= 2 GiB of ncclUint8 (2^23 rows unsliced on one rank: 2 GiB to itself; 1 GiB and 4 x 512 MiB are right).
+      // On W GPUs a peer's chunk of a 2^24-row commitment is 4 GiB / W^2, so this only matters for W <= 2 - but a silent wrong root is not an acceptable failure mode.
+      auto sendrecv = [&](const u8* sp, int to, u8* rp, int from, size_t n, msrt::Stream* st) -> int {
+        int er = 0;
+        for (size_t o = 0; o < n && !er; o += rccl_max_piece) {
+          const size_t len = n - o < rccl_max_piece ? n - o : rccl_max_piece;
+          if (sp) er = R.send(const_cast<u8*>(sp) + o, len, 1 /* ncclUint8 */, to, rccl_comm, st);
+          if (rp && !er) er = R.recv(rp + o, len, 1, from, rccl_comm, st);
+        }
+        return er;
+      };
       if (op == MS_XCHG_ALL_TO_ALL) {
         e = R.group_start();
-        for (int r = 0; r < W && !e; r++) {
-          e = R.send(xs + (size_t)r * bytes, bytes, 1 /* ncclUint8 */, r, rccl_comm, stream);
-          if (!e) e = R.recv(xr + (size_t)r * bytes, bytes, 1, r, rccl_comm, stream);
-        }
+        for (int r = 0; r < W && !e; r++) e = sendrecv(xs + (size_t)r * bytes, r, xr + (size_t)r * bytes, r, bytes, stream);
         const int e2 = R.group_end();
         if (!e) e = e2;
       } else if (op == MS_XCHG_GATHER) {   // to rank 0 only: chunk r of its receive buffer from rank r
         e = R.group_start();
-        if (sh_rank != 0) { if (!e) e = R.send(xs, bytes, 1, 0, rccl_comm, stream); }
-        else for (int r = 1; r < W && !e; r++) e = R.recv(xr + (size_t)r * bytes, bytes, 1, r, rccl_comm, stream);
+        if (sh_rank != 0) { if (!e) e = sendrecv(xs, 0, nullptr, 0, bytes, stream); }
+        else for (int r = 1; r < W && !e; r++) e = sendrecv(nullptr, 0, xr + (size_t)r * bytes, r, bytes, stream);
         const int e2 = R.group_end();
         if (!e) e = e2;
         if (!e && sh_rank == 0 && msrt::d2d(xr, xs, bytes, stream)) e = -1;
-      } else if (op == MS_XCHG_ALL_GATHER) e = R.all_gather(xs, xr, bytes, 1, rccl_comm, stream);
+      } else if (op == MS_XCHG_ALL_GATHER) {
+        if (bytes <= rccl_max_piece) e = R.all_gather(xs, xr, bytes, 1, rccl_comm, stream);
+        else {   // (a gathered round polynomial of a <= 2-rank world: the same pieces as grouped send / recv)
+          e = R.group_start();
+          for (int r = 0; r < W && !e; r++) e = sendrecv(xs, r, xr + (size_t)r * bytes, r, bytes, stream);
+          const int e2 = R.group_end();
+          if (!e) e = e2;
+        }
+      }
       else if (op == MS_XCHG_ALL_REDUCE_MIN_U64) e = R.all_reduce(xs, xs, bytes / 8, 5 /* ncclUint64 */, 3 /* ncclMin */, rccl_comm, stream);
       else e = R.all_reduce(xs, xs, bytes, 1, 0 /* ncclSum */, rccl_comm, stream);
       if (e) { err = std::string("RCCL error ") + std::to_string(e) + (R.err_string ? std::string(": ") + R.err_string(e) : std::string()); return MS_ERR_HIP; }
@@ -187,10 +205,12 @@ template <class F> struct Ctx : CtxBase {
       CK(msrt::event_record(ev_hash[sl], stream));                 // slice hashed (incl. its deferred pad-only blocks)
       CK(msrt::stream_wait_event(comm_stream, ev_hash[sl]));
       int e = R.group_start();
-      for (int r = 0; r < sh_world && !e; r++) {
-        e = R.send(xs + off + (size_t)r * stride, bytes, 1 /* ncclUint8 */, r, rccl_comm, comm_stream);
-        if (!e) e = R.recv(xr + off + (size_t)r * stride, bytes, 1, r, rccl_comm, comm_stream);
-      }
+      for (int r = 0; r < sh_world && !e; r++)
+        for (size_t o = 0; o < bytes && !e; o += rccl_max_piece) {   // (pieces: see exchange)
+          const size_t len = bytes - o < rccl_max_piece ? bytes - o : rccl_max_piece;
+          e = R.send(xs + off + (size_t)r * stride + o, len, 1 /* ncclUint8 */, r, rccl_comm, comm_stream);
+          if (!e) e = R.recv(xr + off + (size_t)r * stride + o, len, 1, r, rccl_comm, comm_stream);
+        }
       const int e2 = R.group_end();
       if (!e) e = e2;
       if (e) { err = std::string("RCCL error ") + std::to_string(e) + (R.err_string ? std::string(": ") + R.err_string(e) : std::string()); return MS_ERR_HIP; }
@@ -998,6 +1018,7 @@ template <class F> struct Ctx : CtxBase {
     if (const char* e = getenv("MS_SHARD_GATHER_CHUNK")) { long v = atol(e); if (v >= 64) shard_gather_chunk = (size_t)v & ~(size_t)63; }
     if (const char* e = getenv("MS_SHARD_SLICES")) { int v = atoi(e); if (v >= 1 && v <= 64) { shard_slices = v; shard_slices_set = true; } }
     if (const char* e = getenv("MS_SHARD_SLICE_MIN")) { long v = atol(e); if (v >= 1) shard_slice_min = (size_t)v; }
+    if (const char* e = getenv("MS_RCCL_MAX_PIECE")) { long long v = atoll(e); if (v >= 64 && v <= ((long long)1 << 30)) rccl_max_piece = (size_t)v & ~(size_t)63; }
     CK(msrt::set_device(dev));
     CK(msrt::stream_create(&own_stream));
     stream = own_stream;

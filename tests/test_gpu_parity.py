@@ -625,11 +625,14 @@ def test_trace_upload_from_page_locked_memory(monkeypatch, upload):
 
 
 @pytest.mark.parametrize("field,log_n,rccl,env,root_only", [(0, 12, False, {}, False), (0, 16, True, {}, False), (1, 14, True, {"MS_SHARD_SLICES": "4", "MS_SHARD_SLICE_MIN": "64"}, True),
-                                                           (0, 18, True, {"MS_SHARD_SLICES": "4", "MS_SHARD_MIN_LEAVES": "32768"}, False)])
+                                                           (0, 18, True, {"MS_SHARD_SLICES": "4", "MS_SHARD_MIN_LEAVES": "32768"}, False),
+                                                           (0, 16, True, {"MS_RCCL_MAX_PIECE": "4096"}, True), (1, 14, True, {"MS_RCCL_MAX_PIECE": "1024", "MS_SHARD_SLICES": "2", "MS_SHARD_SLICE_MIN": "64"}, False)])
 def test_sharded_code_paths_on_one_rank_on_gpu(monkeypatch, field, log_n, rccl, env, root_only):
     """The sharded prover on a one-rank world on the real kernels (MS_SHARD_WORLD1=1).  rccl=True: the exchanges are RCCL calls inside the library on a one-rank communicator -
     grouped ncclSend / ncclRecv (to itself), ncclAllGather, ncclAllReduce, the sliced digest exchange on its own stream behind events, the gather to rank 0 - so the RCCL branch,
-    which no multi-GPU box has run yet, executes through whole proofs with real buffers and stream ordering, bit-exact against the oracle (2^18 rows with the default threshold)."""
+    which no multi-GPU box has run yet, executes through whole proofs with real buffers and stream ordering, bit-exact against the oracle (2^18 rows with the default threshold).
+    MS_RCCL_MAX_PIECE (r05): every transfer cut into pieces of that many bytes - the loop that keeps a single ncclSend / ncclRecv below 2 GiB (RCCL 2.26.6 delivers wrong bytes
+    beyond: test_config3_sharded_form_2p24_rows_matches_unsharded), forced at small sizes."""
     import torch
     monkeypatch.setenv("MS_SHARD_WORLD1", "1")
     monkeypatch.setenv("MS_SHARD_MIN_LEAVES", "64")
@@ -642,3 +645,51 @@ def test_sharded_code_paths_on_one_rank_on_gpu(monkeypatch, field, log_n, rccl, 
     finally:
         orc.set_threads(1)
     assert st[0] >= 3 and st[1] > st[0] and st[2] == 1 and st[3] == 1 and dist_rounds >= 2
+
+
+def _env_setter(monkeypatch):
+    def set_env(k, v):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, v)
+    return set_env
+
+
+def test_config3_sharded_form_2p24_rows_matches_unsharded(monkeypatch):
+    """BASELINE configs[3] in its SHARDED form at full size - 2^24-row Goldilocks proof (4 GiB digest exchanges, ~1 GiB proof, 12 distributed rounds) through
+    the sharded code paths on a one-rank RCCL communicator inside the library: plain and sliced digest exchange, proof on every rank and on rank 0 only.  Trace root, LDE
+    root, DEEP values, every FRI round's B, root and length and the SHA-256 of the FRI blob equal the UNSHARDED proof of the same library, which
+    test_config3_2p24_rows_bit_exact_vs_oracle pins to the oracle."""
+    import torch
+    variants = [(True, {}, False), (True, {"MS_SHARD_SLICES": "4"}, True), (True, {"MS_SHARD_SLICES": "4"}, False), (True, {}, True)]
+    res = pc.case_sharded_one_rank_matches_unsharded(lambda f: ms.Context(f), 0, 24, variants, _env_setter(monkeypatch), device=torch.device("cuda", 0))
+    for st, dist_rounds in res:
+        assert st[0] >= 10 and st[1] > st[0] and st[2] == 1 and st[3] == 1 and dist_rounds >= 10, (st, dist_rounds)
+
+
+def test_config4_sharded_form_wide_air_2p22_rows_matches_unsharded(monkeypatch):
+    """BASELINE configs[4] in its SHARDED form at full size - the 64-column, c = 128 wide AIR at 2^22 rows (2.5 KB leaf messages, 1 GiB digest exchange
+    for the LDE) on the one-rank RCCL world, plain and sliced, against the unsharded proof of the same library (pinned to the oracle by
+    test_config4_wide_air_2p22_rows_bit_exact_vs_oracle)."""
+    import torch
+    variants = [(True, {}, False), (True, {"MS_SHARD_SLICES": "4"}, True)]
+    res = pc.case_sharded_one_rank_matches_unsharded(lambda f: ms.Context(f), 0, 22, variants, _env_setter(monkeypatch), wide_w=64, device=torch.device("cuda", 0), seed=5)
+    for st, dist_rounds in res:
+        assert st[0] >= 8 and st[1] > st[0] and dist_rounds >= 8, (st, dist_rounds)
+
+
+def test_sharded_2p22_rows_on_4_gloo_ranks_matches_unsharded():
+    """a 2^22-row Fibonacci proof over FOUR ranks sharing this GPU (gloo; default MS_SHARD_MIN_LEAVES: LDE + ten FRI rounds sharded, round polynomials
+    distributed): every rank's outputs equal an UNSHARDED proof of the same library computed by that rank (shard_worker.py gpu-self)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29967", os.path.join(here, "shard_worker.py"), "0", "22", "8", "32768", "gpu-self"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    calls = {int(k): v for k, v in res["calls"].items()}
+    assert res["world"] == 4 and calls[0] >= 10 and calls[2] == 1 and calls[3] == 1 and res["dist_rounds"] >= 9, res

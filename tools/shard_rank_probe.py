@@ -4,7 +4,7 @@ payload in every peer's place - no peers exist), so the kernels run on operands 
 ends with "leaf not found", after all its work).  Gives, per world size: wall time of the rank's proof, kernel time partitioned / replicated (HIP events per launch,
 ms_profile), collective calls - next to the unsharded proof on the same GPU.  Strong-scaling bound = unsharded time / (rank time + link time of the exchanges).
   python3 tools/shard_rank_probe.py --log-rows 24 --worlds 2 4 8"""
-import argparse, ctypes as C, json, os, sys, time
+import argparse, ctypes as C, hashlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -48,6 +48,17 @@ class Stub:
         return 0
 
 
+def fingerprint(hs):
+    """Everything a proof outputs, compactly: transcript, both trace commitments, DEEP values, FRI roots, SHA-256 of the FRI blob (read back from HBM)."""
+    p = hs.last_proof(read_fri_proof=True)
+    return {"arthur": hashlib.sha256(p.arthur).hexdigest(), "trace_root": p.trace_commit.hex(), "lde_root": p.constrain_trace_commit.hex(),
+            "deep_values": hashlib.sha256(p.constrain_queries.tobytes() + p.validity_queries.tobytes()).hexdigest(),
+            "fri_roots": hashlib.sha256(b"".join(p.fri_roots)).hexdigest(), "fri_blob": hashlib.sha256(p.fri_proof.blob).hexdigest(), "fri_blob_bytes": len(p.fri_proof.blob)}
+
+
+UNSHARDED = {}
+
+
 def one(world, dist):
     os.environ["MS_SHARD_DIST"] = str(dist)
     ctx = ms.Context(0)
@@ -63,6 +74,9 @@ def one(world, dist):
         assert rc in ok, (rc, ctx.last_error())
     prove()
     torch.cuda.synchronize()
+    if world == 1 and not UNSHARDED:   # the reference the one-rank sharded legs below are checked against (the stub worlds compute on wrong values by construction)
+        ctx.check(hs.prove_raw(tt, trace_device_ptr=d_trace.data_ptr(), read_fri_proof=True))
+        UNSHARDED.update(fingerprint(hs))
     ts = []
     for _ in range(args.reps):
         t0 = time.perf_counter(); prove(); ts.append((time.perf_counter() - t0) * 1e3)
@@ -105,7 +119,11 @@ if os.environ.get("MS_PROBE_W1_RCCL") == "1":
         st0 = ctx.shard_stats()
         prove()
         st1 = ctx.shard_stats()
-        print(json.dumps({"world": 1, "rccl_one_rank": True, "digest_exchange_slices": int(slices), "log_rows": args.log_rows, "ms_wall_min": round(min(ts), 3), "ms_wall_all": [round(t, 3) for t in ts],
+        # this leg is no longer timing-only - the proof the sharded code paths produce must be the unsharded one, bit for bit
+        ctx.check(hs.prove_raw(tt, trace_device_ptr=d_trace.data_ptr(), read_fri_proof=True))
+        fp = fingerprint(hs)
+        assert fp == UNSHARDED, {"sharded_one_rank": fp, "unsharded": UNSHARDED}
+        print(json.dumps({"world": 1, "rccl_one_rank": True, "matches_unsharded": True, "fri_blob_bytes": fp["fri_blob_bytes"], "digest_exchange_slices": int(slices), "log_rows": args.log_rows, "ms_wall_min": round(min(ts), 3), "ms_wall_all": [round(t, 3) for t in ts],
                           "overhead_vs_unsharded_ms": round(min(ts) - base["ms_wall_min"], 3), "collective_calls_per_proof": [st1[i] - st0[i] for i in range(4)]}), flush=True)
         sh.close(); ctx.close()
     del os.environ["MS_SHARD_WORLD1"], os.environ["MS_SHARD_SLICES"]
