@@ -164,7 +164,7 @@ class Lanes:
         self.ms, self.io, self.n, self.io_mode = ms, io, inflight, io_mode
         self.samples = [set() for _ in range(inflight)]
         # lane i starts i ms after lane 0 (inside the timed region): proofs that start together stay in lock-step for tens of proofs - all lanes in the latency-bound late FRI
-        # rounds at the same time, then all in the LDE hashing - and a 20-step run measured 246 proofs/s that way against 256 with the stagger (profiles/r03_lane_stagger.log)
+        # rounds at the same time, then all in the LDE hashing - and a 20-step run measured 246 proofs/s that way against 256 with the stagger (r03; profiles/HISTORY.md)
         self.stagger_ms = float(os.environ.get("MS_BENCH_STAGGER_MS", "1"))
         steps = (1 << log_rows) - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
         self.ctxs = [ms.Context(field, device=device_index, lib_path=lib) for _ in range(inflight)]
@@ -581,7 +581,7 @@ def main():
             if big:
                 r1 = float(big["grid_threads"]) / 64.0 * float(big["valu_wave_instr_per_thread"]) / (float(big["avg_us"]) * 1e-6)
                 whole["largest_leaf_launch"] = {"wave_instr_per_s": r1, "frac_of_quad_cycle_peak": r1 / peak_quad, "source": "profiles/" + sq_name + " (LDE leaf hashing: grid, instructions per thread and duration of the profiled run)"}
-            peak_lab = N_SIMD * 2.2e9 / 3.65          # tools/sha_lab.hip (profiles/r02_sha_lab.log): the same compression code on registers only, 4-8 waves/SIMD: 3.5-3.8 clocks per instruction
+            peak_lab = N_SIMD * 2.2e9 / 3.65          # tools/sha_lab.hip (profiles/r04_sha_lab.log): the same compression code on registers only, 4-8 waves/SIMD: 3.5-3.8 clocks per instruction
             for v in rv.values():
                 v["frac_of_sha_lab_rate"] = v["achieved_wave_instr_per_s"] / peak_lab
             whole["frac_of_sha_lab_rate"] = rate_all / peak_lab
@@ -593,7 +593,7 @@ def main():
                                     "peak_quad_cycle": peak_quad, "peak_quad_cycle_basis": "one wave64 VALU instruction per SIMD per 4 clocks, 1024 SIMDs, 2.2 GHz (the clock rocprofv3 GRBM_GUI_ACTIVE shows under the hash kernels): "
                                     "the issue rate of the carry / 64-bit / rotate / multiply / v_add3 class (tools/valu_rate.hip; simple 32-bit operations issue at ~2.5 cycles) and the average the large SHA-256 launches reach (96 %)", "peak_guide_basis": "MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op = 2 cycles, 2.4 GHz",
                                     "peak_measured": peak_meas, "peak_measured_basis": "3.4 cycles per VALU instruction: what register-resident integer butterfly code sustains at >= 4 waves/SIMD whatever the opcode mix "
-                                    "(tools/ntt_lab.hip, profiles/r02_ntt_lab.log); the per-opcode costs of tools/valu_rate.hip did not carry over to mixed code",
+                                    "(tools/ntt_lab.hip, profiles/r04_ntt_lab.log); the per-opcode costs of tools/valu_rate.hip did not carry over to mixed code",
                                     "instr_source": "profiles/" + sq_name + " (rocprofv3 --pmc SQ_INSTS_VALU per dispatch; constants, not measured in this run)",
                                     "instr_profile_taken_from_this_kernel_source": profile_is_current(sq_name[:3]),
                                     "times": "live: HIP events of this run, one proof alone (small tree levels are latency-bound, which lowers the class average)", "kernels": rv}

@@ -46,6 +46,7 @@ extern "C" {
     // ---- Stark::prove stages (src/starks.rs:59-169)
     pub fn ms_trace_commit(ctx: *mut ms_ctx, trace_rowmajor: *const u64, n: usize, w: usize, lpn: usize, root: *mut u8 /* [32] */) -> c_int;
     pub fn ms_trace_commit_device(ctx: *mut ms_ctx, d_trace_rowmajor: *const c_void, n: usize, w: usize, lpn: usize, root: *mut u8) -> c_int;
+    pub fn ms_trace_upload_async(ctx: *mut ms_ctx, trace_rowmajor: *const u64, n: usize, w: usize) -> c_int;
     pub fn ms_interpolate(ctx: *mut ms_ctx) -> c_int;
     pub fn ms_polys_lincomb(ctx: *mut ms_ctx, scalars: *const u64, idx: *const c_int, k: c_int) -> c_int;
     pub fn ms_polys_append(ctx: *mut ms_ctx, coeffs: *const u64, n: usize) -> c_int;
@@ -72,6 +73,7 @@ extern "C" {
     pub fn ms_fri_proof_read_async(ctx: *mut ms_ctx, out: *mut u8) -> c_int;
     pub fn ms_fri_proof_wait(ctx: *mut ms_ctx) -> c_int;
     pub fn ms_io_engine(ctx: *const ms_ctx) -> c_int;
+    pub fn ms_io_runtime_path() -> *const c_char;
     // ---- Tree trait (src/merkle.rs:8-30) on its own
     pub fn ms_merkle_commit(ctx: *mut ms_ctx, leafs: *const u64, leaf_num: usize, ext: c_int, lpn: usize, ic: usize,
                             nodes_out: *mut u8, nodes_cap: usize, nnodes: *mut usize, root: *mut u8) -> c_int;

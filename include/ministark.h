@@ -136,6 +136,12 @@ int ms_trace_commit(ms_ctx* ctx, const uint64_t* trace_rowmajor, size_t N, size_
 /*      Same, for a trace already resident in HBM (device pointer, same layout).  Elements must be canonical (< p) like the
  *      host path's; the range check runs inside the transposing kernel and the call returns MS_ERR_ARG if any element is >= p. */
 int ms_trace_commit_device(ms_ctx* ctx, const void* d_trace_rowmajor, size_t N, size_t w, size_t lpn, uint8_t root[32]);
+/* Optional prefetch of the NEXT proof's trace (r05): queues the copy of a page-locked (ms_pinned_alloc) row-major N x w trace into the device buffer the proof in
+ * flight does not use, on an SDMA engine, and returns at once; the ms_trace_commit that later names the same pointer and shape finds the trace on the device instead
+ * of waiting for the transfer.  Callable any time after the previous ms_trace_commit has returned - typically right behind it, so that the ~24 MiB travel while
+ * the current proof computes.  A hint: pageable memory, MS_UPLOAD=hip or a busy engine queue nothing (MS_OK all the same) and ms_trace_commit uploads as before.
+ * `trace` must stay valid and unchanged until that ms_trace_commit returns; one prefetch in flight per context (a second one waits for the first). */
+int ms_trace_upload_async(ms_ctx* ctx, const uint64_t* trace_rowmajor, size_t N, size_t w);
 /* 1.2a TraceTable::get_trace_polys: per-column INTT.  air.rs:147-160. */
 int ms_interpolate(ms_ctx* ctx);
 /* 1.2b constraint polynomial appended as sum_t scalars[t] * poly[idx[t]] (the
@@ -189,6 +195,14 @@ int ms_fri_proof_wait(ms_ctx* ctx);
  * never a blit kernel; the default for ms_fri_proof_read_async when the HSA runtime binds), 0 = the HIP runtime's copy (hipMemcpyAsync; env MS_READBACK=hip, the
  * blocking ms_fri_proof_read, or the fall-back when the engine refused the copy). */
 int ms_io_engine(const ms_ctx* ctx);
+/* which HSA runtime the copy engines were bound through: the path of the libhsa-runtime64 ALREADY mapped into the process (the one HIP itself runs on; the library
+ * never loads a runtime of its own), "" while none is bound.  A profiled or otherwise mixed-runtime run can be recognised in its records by this. */
+const char* ms_io_runtime_path(void);
+/* Failure semantics of the engine copies (upload and read-back alike): an engine that refuses a copy -> this context uses the HIP runtime's copies from then on; a copy
+ * the engine reports as FAILED -> done again through the HIP runtime, the call succeeds if that does; a copy that does not COMPLETE within 20 s (env
+ * MS_SDMA_TIMEOUT_S) -> MS_ERR_HIP, and the context is POISONED: the engine may still be accessing the caller's buffer and the device blob, so every later entry
+ * point returns MS_ERR_STATE (ms_last_error says why), nothing is reused, and only ms_destroy is valid - it waits for the transfer without limit, then frees.
+ * The caller must keep its buffer alive until ms_destroy has returned. */
 /* ms_fri_query with the FriProof written WHERE IT IS READ: the query-phase kernels store the MSFP blob straight into `out` - page-locked
  * host memory from ms_pinned_alloc (mapped into the device's address space) or device memory - of `cap` bytes; no read-back copy.  The
  * blob is complete when the call returns.  *len receives the blob size; with cap smaller than that nothing is computed and MS_ERR_ARG is

@@ -33,15 +33,13 @@ def library_path():
 
 
 def build_library(force=False):
-    """hipcc cross-compile for gfx950 (works without a GPU)."""
+    """hipcc cross-compile for gfx950 (works without a GPU): `make` in csrc/, one object per translation unit, side by side."""
     so = library_path()
-    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "ministark.h"))
-    if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
-        return so
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-x", "hip",   # (unroll hints the optimiser declines are not errors)
-           os.path.join(_HERE, "csrc", "ministark.cpp"), "-o", so]
-    subprocess.check_call(cmd)
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    jobs = str(max(1, min(8, len(os.sched_getaffinity(0)))))
+    subprocess.check_call(["make", "-C", csrc, "-j", jobs], stdout=subprocess.DEVNULL)   # (no-op when up to date)
     return so
 
 
@@ -168,6 +166,30 @@ class Context:
         if rc == 0:
             self.N, self.w = N, w
         return rc, bytes(root)
+
+    def trace_commit_ptr(self, host_ptr, N, w, lpn):
+        """ms_trace_commit on a raw host pointer (page-locked memory from pinned_alloc: the trace then travels on an SDMA engine)."""
+        root = (C.c_uint8 * 32)()
+        rc = self.L.ms_trace_commit(self.h, C.c_void_p(host_ptr), C.c_size_t(N), C.c_size_t(w), C.c_size_t(lpn), root)
+        if rc == 0:
+            self.N, self.w = N, w
+        return rc, bytes(root)
+
+    def trace_upload_async(self, host_ptr, N, w):
+        """ms_trace_upload_async: prefetch of the NEXT proof's page-locked trace while the current proof computes (a hint; MS_OK also when nothing was queued)."""
+        return self.L.ms_trace_upload_async(self.h, C.c_void_p(host_ptr), C.c_size_t(N), C.c_size_t(w))
+
+    def pinned_alloc(self, nbytes):
+        self.L.ms_pinned_alloc.restype = C.c_void_p
+        return self.L.ms_pinned_alloc(C.c_size_t(nbytes))
+
+    def pinned_free(self, ptr):
+        self.L.ms_pinned_free.argtypes = [C.c_void_p]
+        self.L.ms_pinned_free(C.c_void_p(ptr))
+
+    def io_runtime_path(self):
+        self.L.ms_io_runtime_path.restype = C.c_char_p
+        return (self.L.ms_io_runtime_path() or b"").decode()
 
     def trace_commit_device(self, dev_ptr, N, w, lpn):
         root = (C.c_uint8 * 32)()

@@ -39,7 +39,7 @@ MS_HD u32 rotr32(u32 x, int n) {
 }
 MS_HD u32 bswap32(u32 x) { return __builtin_bswap32(x); }
 // gfx950 v_bitop3_b32 (arbitrary 3-input bit function) issues in ~2.7 cycles per wave-instruction where v_bfi_b32 and
-// the other 3-source VOP3 ops take ~4.5 (tools/valu_rate.hip, profiles/r01_valu_issue_rate.txt).
+// the other 3-source VOP3 ops take ~4.5 (tools/valu_rate.hip, profiles/r04_valu_issue_rate.txt).
 MS_HD u32 ch3(u32 e, u32 f, u32 g) {  // e ? f : g
 #if defined(__HIP_DEVICE_COMPILE__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
   return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA);

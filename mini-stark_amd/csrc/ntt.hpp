@@ -458,7 +458,7 @@ template <class F, bool INV, int K, int TH> struct PassKernelK {
 //                                 contiguous block of r0 * r elements
 // What was tried on these tiles and lost (cross-tile register prefetch, LDS-DMA prefetch with a counted vmcnt, the expanded
 // coefficients kept in registers for the first sub-round, 16-column 1024-thread tiles, the timing-only ablation branches) lives in
-// the round-2 history of this file and in profiles/r02_*.log, not in the product kernel.
+// the round-2 history of this file and in profiles/HISTORY.md, not in the product kernel.
 template <int K, int NSUB> struct Digits2 {
   // digit sizes, top digit first: NSUB == 2: (ceil(K/2), floor(K/2)); NSUB == 3: last = K/3, middle = (K - last)/2, top = the rest
   // (10: 4,3,3   9: 3,3,3   8: 3,3,2   7: 3,2,2)

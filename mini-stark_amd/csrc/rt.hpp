@@ -46,7 +46,7 @@ inline int event_record(Event*, Stream*) { return 0; }
 inline int event_elapsed_ms(float* ms, Event*, Event*) { *ms = 0.f; return 0; }
 inline int stream_wait_event(Stream*, Event*) { return 0; }
 inline int event_sync(Event*) { return 0; }
-inline bool is_pinned_host(const void*) { return false; }
+inline bool is_pinned_host(const void*) { const char* e = std::getenv("MS_EMU_SDMA"); return e && *e; }   // (the scripted engine of the failure-handling tests takes any host memory)
 template <class K>
 inline int launch(Stream*, unsigned gx, unsigned gy, int threads, size_t lds_bytes, const typename K::Params& p) {
   std::vector<unsigned char> lds(lds_bytes + 16);
@@ -69,20 +69,38 @@ struct Rccl {
   static Rccl& get() { static Rccl r; return r; }
   int load() { return 1; }
 };
-// no copy engines in the emulation build: the read-back is the plain copy
+// No copy engines in the emulation build: the read-back is the plain copy - unless MS_EMU_SDMA is set (tests of the boundary's failure handling): a scripted
+// engine whose copies are memcpy's.  "ok": every copy completes; "hang": copies are accepted and never complete (wait() reports a timeout at once; an unlimited
+// wait - ms_destroy - returns, or the test itself would hang); "fail": copies are accepted and complete with a NEGATIVE signal (what hsa_ext_amd.h documents
+// for a failed asynchronous copy), nothing is written; "hang-upload" / "fail-upload": the same for host-to-device copies only.
 struct Sdma {
   struct Signal { unsigned long long handle = 0; };
+  long long sig_val[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned nsig = 0;
   static Sdma& get() { static Sdma s; return s; }
-  int load() { return 1; }
-  int bind_device(int, int*) { return 1; }
-  int signal_create(Signal*) { return 1; }
+  static const char* mode() { const char* e = std::getenv("MS_EMU_SDMA"); return (e && *e) ? e : nullptr; }
+  static bool is(const char* m) { const char* e = mode(); return e && !std::strcmp(e, m); }
+  int load() { return mode() ? 0 : 1; }
+  int bind_device(int, int* g) { if (!mode()) return 1; *g = 0; return 0; }
+  int signal_create(Signal* s) { if (!mode()) return 1; s->handle = 1 + (nsig++ & 7); return 0; }
   void signal_destroy(Signal) {}
-  int copy_d2h(int, void*, const void*, size_t, Signal, unsigned) { return 1; }
-  int copy_h2d(int, void*, const void*, size_t, Signal, unsigned) { return 1; }
-  unsigned h2d_engine(int) { return 0; }
-  int wait(Signal, double) { return 1; }
-  unsigned d2h_engine(int) { return 0; }
-  bool unavailable() const { return true; }
+  int copy_d2h(int, void* d, const void* s_, size_t n, Signal sg, unsigned) {
+    if (!mode()) return 1;
+    if (is("hang")) { sig_val[sg.handle - 1] = 1; return 0; }
+    if (is("fail")) { sig_val[sg.handle - 1] = -1; return 0; }
+    std::memcpy(d, s_, n); sig_val[sg.handle - 1] = 0; return 0;
+  }
+  int copy_h2d(int, void* d, const void* s_, size_t n, Signal sg, unsigned) {
+    if (!mode()) return 1;
+    if (is("hang") || is("hang-upload")) { sig_val[sg.handle - 1] = 1; return 0; }
+    if (is("fail") || is("fail-upload")) { sig_val[sg.handle - 1] = -1; return 0; }
+    std::memcpy(d, s_, n); sig_val[sg.handle - 1] = 0; return 0;
+  }
+  unsigned h2d_engine(int) { return mode() ? 1 : 0; }
+  unsigned d2h_engine(int) { return mode() ? 1 : 0; }
+  // 0: complete; 1: not within `seconds` (seconds < 0: no limit); -1: the copy FAILED
+  int wait(Signal sg, double seconds) { const long long v = sig_val[sg.handle - 1]; if (v == 0) return 0; if (v < 0) return -1; return seconds < 0 ? 0 : 1; }
+  bool unavailable() const { return !mode(); }
+  const char* runtime_path() const { return mode() ? "emulated copy engine (MS_EMU_SDMA)" : ""; }
 };
 }  // namespace msrt
 // ---- cooperative kernels (K::run with workgroup barriers INSIDE the function, per-thread state alive across them): every thread of a
@@ -162,8 +180,7 @@ namespace msrt {
 typedef ihipStream_t Stream;
 inline int malloc_dev(void** p, size_t n) { return (int)hipMalloc(p, n ? n : 1); }
 inline int free_dev(void* p) { return (int)hipFree(p); }
-// MS_PINNED_FLAGS (experiments): hipHostMalloc flags of the page-locked buffers, e.g. 0x80000000 = hipHostMallocNonCoherent
-inline int malloc_host(void** p, size_t n) { const char* e = getenv("MS_PINNED_FLAGS"); return (int)hipHostMalloc(p, n ? n : 1, e ? (unsigned)strtoul(e, nullptr, 0) : hipHostMallocDefault); }
+inline int malloc_host(void** p, size_t n) { return (int)hipHostMalloc(p, n ? n : 1, hipHostMallocDefault); }
 inline int free_host(void* p) { return (int)hipHostFree(p); }
 inline int h2d(void* d, const void* h, size_t n, Stream* s) { return (int)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); }
 inline int d2h(void* h, const void* d, size_t n, Stream* s) { return (int)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s); }
@@ -242,7 +259,9 @@ inline int Rccl::load() {
 // hsa_amd_memory_async_copy_on_engine with force_copy_on_sdma queues the copy on a chosen SDMA engine; completion is an HSA signal the host waits on.
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
+#include <link.h>
 #include <mutex>
+#include <string>
 namespace msrt {
 struct Sdma {
   typedef hsa_signal_t Signal;
@@ -258,6 +277,7 @@ struct Sdma {
   decltype(&hsa_amd_memory_async_copy_on_engine) f_copy = nullptr;
   decltype(&hsa_amd_memory_copy_engine_status) f_status = nullptr;
   decltype(&hsa_amd_memory_get_preferred_copy_engine) f_pref = nullptr;
+  decltype(&hsa_amd_pointer_info) f_ptr_info = nullptr;
   hsa_agent_t cpu{0}; bool have_cpu = false;
   struct Gpu { hsa_agent_t agent; uint32_t bdf, domain; unsigned d2h_engine, h2d_engine; };
   std::vector<Gpu> gpus;
@@ -276,26 +296,52 @@ struct Sdma {
     }
     return HSA_STATUS_SUCCESS;
   }
-  // 0 on success.  MS_HSA_LIB names the library (default: the HSA runtime already mapped into the process, else libhsa-runtime64.so.1)
+  // 0 on success.  Binds ONLY the HSA runtime the process already runs on: the loaded objects are enumerated (dl_iterate_phdr), the one named
+  // libhsa-runtime64* is re-opened with RTLD_NOLOAD - whatever directory or soname it came from (a ROCm install, the PyTorch wheel's bundled copy) - and with
+  // several copies mapped (a profiler preloading its own) the one next to the libamdhip64 this library is linked against wins, else none.  Nothing is ever
+  // loaded: a second runtime would open KFD again and know none of HIP's allocations.  No runtime found = state 2: the caller keeps hipMemcpyAsync.
+  std::string path;                                        // what was bound (ms_io_runtime_path)
+  struct Scan { std::vector<std::string> hsa; std::string hip_dir; };
+  static int scan_cb(struct dl_phdr_info* info, size_t, void* data) {
+    Scan* sc = reinterpret_cast<Scan*>(data);
+    const char* n = info->dlpi_name;
+    if (!n || !*n) return 0;
+    const char* base = strrchr(n, '/'); base = base ? base + 1 : n;
+    if (!strncmp(base, "libhsa-runtime64", 16)) sc->hsa.push_back(n);
+    return 0;
+  }
   int load() {
     std::lock_guard<std::mutex> lk(mu);
     if (state) return state == 1 ? 0 : 1;
     state = 2;
-    const char* names[] = {getenv("MS_HSA_LIB"), "libhsa-runtime64.so.1", "libhsa-runtime64.so", "/opt/rocm/lib/libhsa-runtime64.so.1"};
-    void* h = nullptr;
-    for (const char* n : names) { if (n && *n) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; } }   // the copy HIP initialised, not a second runtime
-    if (!h) for (const char* n : names) { if (n && *n) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; } }
+    Scan sc;
+    dl_iterate_phdr(&scan_cb, &sc);
+    { Dl_info di; if (dladdr(reinterpret_cast<const void*>(&hipStreamSynchronize), &di) && di.dli_fname) { std::string f = di.dli_fname; const size_t k = f.rfind('/'); sc.hip_dir = k == std::string::npos ? std::string() : f.substr(0, k); } }
+    std::string pick;
+    if (sc.hsa.size() == 1) pick = sc.hsa[0];
+    else for (const std::string& c : sc.hsa) { const size_t k = c.rfind('/'); if (k != std::string::npos && c.substr(0, k) == sc.hip_dir) { pick = c; break; } }
+    if (pick.empty()) return 1;
+    void* h = dlopen(pick.c_str(), RTLD_NOW | RTLD_NOLOAD);   // a handle on the mapped copy; NOLOAD: never a fresh one
     if (!h) return 1;
 #define MS_HSA_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(h, name)); if (!field) return 1
     MS_HSA_SYM(f_init, "hsa_init"); MS_HSA_SYM(f_iterate, "hsa_iterate_agents"); MS_HSA_SYM(f_agent_info, "hsa_agent_get_info");
     MS_HSA_SYM(f_sig_create, "hsa_signal_create"); MS_HSA_SYM(f_sig_destroy, "hsa_signal_destroy"); MS_HSA_SYM(f_sig_store, "hsa_signal_store_relaxed");
     MS_HSA_SYM(f_sig_wait, "hsa_signal_wait_scacquire"); MS_HSA_SYM(f_copy, "hsa_amd_memory_async_copy_on_engine"); MS_HSA_SYM(f_status, "hsa_amd_memory_copy_engine_status");
+    MS_HSA_SYM(f_ptr_info, "hsa_amd_pointer_info");
 #undef MS_HSA_SYM
     f_pref = reinterpret_cast<decltype(f_pref)>(dlsym(h, "hsa_amd_memory_get_preferred_copy_engine"));   // optional (HSA AMD extension 1.8)
-    if (f_init() != HSA_STATUS_SUCCESS) return 1;            // reference-counted: HIP holds the runtime open already
+    if (f_init() != HSA_STATUS_SUCCESS) return 1;            // reference-counted: HIP initialised this very copy (ms_create made HIP calls before any copy is queued)
     if (f_iterate(&agent_cb, this) != HSA_STATUS_SUCCESS || !have_cpu || gpus.empty()) return 1;
-    lib = h; state = 1;
+    lib = h; path = pick; state = 1;
     return 0;
+  }
+  const char* runtime_path() const { return path.c_str(); }
+  // does THIS runtime know the allocation behind p (device memory of hipMalloc, page-locked host memory of hipHostMalloc)?  A pointer it has never seen means
+  // the bound runtime is not the one HIP allocates through: no copy is queued on it
+  bool knows(const void* p) {
+    hsa_amd_pointer_info_t info; memset(&info, 0, sizeof info); info.size = sizeof info;
+    if (f_ptr_info(const_cast<void*>(p), &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS) return false;
+    return info.type != HSA_EXT_POINTER_TYPE_UNKNOWN;
   }
   // HIP device -> HSA agent by PCI address; *gpu_index identifies it in the calls below
   int bind_device(int hip_device, int* gpu_index) {
@@ -336,12 +382,12 @@ struct Sdma {
     *gpu_index = dev_gpu[hip_device];
     return 0;
   }
-  unsigned d2h_engine(int gpu_index) { return gpus[gpu_index].d2h_engine; }
+  unsigned d2h_engine(int gpu_index) { std::lock_guard<std::mutex> lk(mu); return gpus[gpu_index].d2h_engine; }   // (under the mutex: bind_device of another context may rewrite the record - ADVICE r4)
   bool unavailable() const { return state == 2; }   // the HSA runtime could not be bound at all (as opposed to: no engine free at this moment)
-  unsigned h2d_engine(int gpu_index) {
+  unsigned h2d_engine(int gpu_index) {               // callers read it ONCE per copy
+    std::lock_guard<std::mutex> lk(mu);
     Gpu& g = gpus[gpu_index];
     if (!g.h2d_engine && !getenv("MS_SDMA_ENGINE_H2D")) {   // none was free when the device was bound: ask again
-      std::lock_guard<std::mutex> lk(mu);
       uint32_t avail = 0, pref = 0;
       f_status(g.agent, cpu, &avail);
       if (f_pref) f_pref(g.agent, cpu, &pref);
@@ -352,6 +398,7 @@ struct Sdma {
   }
   // page-locked host memory -> device memory of `gpu_index`
   int copy_h2d(int gpu_index, void* dst_dev, const void* src_host, size_t n, Signal sig, unsigned engine) {
+    if (!knows(dst_dev) || !knows(src_host)) return 1;
     f_sig_store(sig, 1);
     return (int)f_copy(dst_dev, gpus[gpu_index].agent, src_host, cpu, n, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)engine, true);
   }
@@ -359,15 +406,20 @@ struct Sdma {
   void signal_destroy(Signal s) { if (s.handle) f_sig_destroy(s); }
   // device memory of `gpu_index` -> page-locked host memory, on SDMA engine `engine`; `sig` reads 0 when the bytes have landed
   int copy_d2h(int gpu_index, void* dst_host, const void* src_dev, size_t n, Signal sig, unsigned engine) {
+    if (!knows(dst_host) || !knows(src_dev)) return 1;
     f_sig_store(sig, 1);
     return (int)f_copy(dst_host, cpu, src_dev, gpus[gpu_index].agent, n, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)engine, true);
   }
-  // 0: complete; 1: not within `seconds`
+  // 0: complete (the signal reads 0); 1: not within `seconds` (seconds < 0: no limit); -1: the copy FAILED - the runtime reports a failed asynchronous copy by
+  // setting the completion signal to a NEGATIVE value (hsa_ext_amd.h), which must not pass for completion
   int wait(Signal sig, double seconds) {
     const uint64_t slice = 2000000000ull;   // the timeout is in ticks of the system timestamp counter (>= 1e8 Hz here): wake up now and then, bound the total by wall time
     timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
     for (;;) {
-      if (f_sig_wait(sig, HSA_SIGNAL_CONDITION_LT, 1, slice, HSA_WAIT_STATE_BLOCKED) < 1) return 0;
+      const hsa_signal_value_t v = f_sig_wait(sig, HSA_SIGNAL_CONDITION_LT, 1, slice, HSA_WAIT_STATE_BLOCKED);
+      if (v == 0) return 0;
+      if (v < 0) return -1;
+      if (seconds < 0) continue;
       timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
       if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > seconds) return 1;
     }
@@ -449,7 +501,7 @@ MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) {
 // ---- bit-level helpers shared by the three builds ---------------------------------------------
 // Arbitrary 3-input bit function, truth table TT indexed by (a << 2 | b << 1 | c).  gfx950: ONE v_bitop3_b32, which issues at
 // the full VALU rate (~2.7 cycles per wave-instruction) where compares, v_cndmask and carry ops cost ~4.5
-// (profiles/r01_valu_issue_rate.txt) and compares additionally route their result through an SGPR pair (2 wait states before use).
+// (profiles/r04_valu_issue_rate.txt) and compares additionally route their result through an SGPR pair (2 wait states before use).
 template <int TT> MS_HD uint32_t ms_bitop3(uint32_t a, uint32_t b, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_bitop3_b32(a, b, c, TT);

@@ -296,7 +296,7 @@ def test_c_abi_never_unwinds(field):
     """SURVEY 8(b) "never unwind" (VERDICT r3 #5): every entry point of libministark runs inside a guard that turns std::bad_alloc into MS_ERR_NOMEM (anything else
     into MS_ERR_HIP).  The emulation build's operator new (hidden: this library's allocations only) can be armed to fail on its N-th call: a whole proof is driven
     with the failure placed at EVERY allocation it makes, one after the other - the stage that hits it must return a negative code (never abort the process, never
-    unwind into ctypes), the stages before it succeed, and afterwards the same context still produces the oracle's proof."""
+    unwind into ctypes), the stages before it succeed, and after EVERY injected failure the same context proves once more with outputs identical to a clean run's (r05)."""
     import ctypes as C
     import numpy as np
     from common import MODULUS, EXT, SplitMix64, fibonacci_trace, fibonacci_closures
@@ -312,27 +312,43 @@ def test_c_abi_never_unwinds(field):
     rounds = 6
     u64p = C.POINTER(C.c_uint64)
 
-    def stages(h):
-        """the reference's prove sequence as raw C calls: yields (name, rc)"""
+    def stages(h, outs=None):
+        """the reference's prove sequence as raw C calls: yields (name, rc); `outs` (a list) collects every output of the proof"""
         rng = SplitMix64(5)
         root = (C.c_uint8 * 32)()
         t = np.ascontiguousarray(trace)
+
+        def keep(*vals):
+            if outs is not None:
+                outs.extend(bytes(v) for v in vals)
         yield "trace_commit", L.ms_trace_commit(h, t.ctypes.data_as(u64p), C.c_size_t(N), C.c_size_t(3), C.c_size_t(6), root)
+        keep(root)
         yield "interpolate", L.ms_interpolate(h)
         for sc, idx in fibonacci_closures(field, N, omega):
             yield "polys_lincomb", L.ms_polys_lincomb(h, (C.c_uint64 * len(sc))(*sc), (C.c_int * len(idx))(*idx), len(sc))
         yield "lde_commit", L.ms_lde_commit(h, C.c_size_t(blowup), C.c_uint64(rng.nonzero(p)), C.c_size_t(6), root)
+        keep(root)
         yield "mix", L.ms_mix(h, C.c_uint64(rng.field(p)))
         out = (C.c_uint64 * (7 * e))()
         yield "eval_ext", L.ms_eval_ext(h, (C.c_uint64 * e)(*[rng.field(p) for _ in range(e)]), 1, out)
+        keep(out)
         yield "fri_begin", L.ms_fri_begin(h, C.c_size_t(blowup), C.c_size_t(rounds), root)
+        keep(root)
         B = (C.c_uint64 * (2 * e))()
         for _ in range(1, rounds):
             yield "fri_deep", L.ms_fri_deep(h, (C.c_uint64 * e)(*[rng.field(p) for _ in range(e)]), B)
             yield "fri_fold_commit", L.ms_fri_fold_commit(h, (C.c_uint64 * e)(*[rng.field(p) for _ in range(e)]), root)
+            keep(B, root)
         yield "fri_query", L.ms_fri_query(h, (C.c_uint64 * 2)(3, 77), 2)
+        if outs is not None:
+            L.ms_fri_proof_size.restype = C.c_size_t
+            L.ms_fri_proof_size.argtypes = [C.c_void_p]
+            blob = (C.c_uint8 * L.ms_fri_proof_size(h))()
+            yield "fri_proof_read", L.ms_fri_proof_read(h, blob)
+            keep(blob)
         yield "ntt", L.ms_ntt(h, (C.c_uint64 * 64)(*range(64)), C.c_size_t(64), C.c_size_t(1), 0)
         yield "merkle_commit", L.ms_merkle_commit(h, (C.c_uint64 * 16)(*range(16)), C.c_size_t(16), 1, C.c_size_t(2), C.c_size_t(2), None, C.c_size_t(0), None, root)
+        keep(root)
 
     # ms_create itself under allocation failure: a negative code, no context
     for k in range(6):
@@ -347,7 +363,8 @@ def test_c_abi_never_unwinds(field):
             assert not h.value
     h = C.c_void_p()
     assert L.ms_create(C.byref(h), 0, field, 1) == 0
-    assert all(rc == 0 for _, rc in stages(h))   # (the first proof also builds the NTT plans, which later proofs reuse)
+    want = []
+    assert all(rc == 0 for _, rc in stages(h, want))   # (the first proof also builds the NTT plans, which later proofs reuse)
     n0 = L.ms_emu_alloc_count()
     assert all(rc == 0 for _, rc in stages(h))
     total = L.ms_emu_alloc_count() - n0
@@ -369,6 +386,11 @@ def test_c_abi_never_unwinds(field):
             assert failed[1] in (ms.ERR_NOMEM, ms.ERR_HIP), (k, failed)
             L.ms_last_error.restype = C.c_char_p
             assert L.ms_last_error(h)            # readable, no allocation needed
+            # a failure caught by the guard must leave no state behind (pending words of the next tree launch, a swapped knob, a half-counted scope) -
+            # the SAME context proves again, and every output of that proof is the clean run's
+            got = []
+            assert all(rc == 0 for _, rc in stages(h, got)), (k, failed)
+            assert got == want, (k, failed, "a proof on the same context after the injected failure differs")
     assert hit == tried, (hit, tried, total)   # every single allocation of a proof, when it fails, surfaces as a negative status of the stage that made it
     L.ms_destroy(h)
     # after all that the library still proves: same bytes as the oracle
@@ -388,3 +410,145 @@ def test_sharded_code_paths_on_one_rank(monkeypatch, field, log_n, blowup, env, 
     subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
     st, dist_rounds = pc.case_sharded_paths_on_one_rank(lambda f: ms.Context(f, lib_path=EMU), field, log_n, blowup, root_only=root_only, base_z=base_z)
     assert st[0] >= 3 and st[1] > st[0] and st[2] == 1 and st[3] == 1 and dist_rounds >= 2
+
+
+def _prove_raw(ctx, field, trace, seed=9, upload=None, read="blocking", prefetch_next=None):
+    """One proof through the raw ABI on `ctx`; returns (rc of the first failing stage or 0, outputs).  upload = host pointer of a copy of the trace in "page-locked"
+    memory (ms_pinned_alloc), read = "blocking" | "async" (ms_fri_proof_read_async + wait into a pinned buffer); prefetch_next = (ptr, N, w) handed to
+    ms_trace_upload_async right behind the trace commitment."""
+    import ctypes as C
+    from common import MODULUS, EXT, SplitMix64, fibonacci_closures
+    from oracle import oracle as orc
+    p, e = MODULUS[field], EXT[field]
+    N, w = trace.shape
+    rng = SplitMix64(seed)
+    outs = []
+    rc, root = ctx.trace_commit_ptr(upload, N, w, 6) if upload else ctx.trace_commit(trace, 6)
+    if rc:
+        return rc, outs
+    outs.append(root)
+    if prefetch_next:
+        rc = ctx.trace_upload_async(*prefetch_next)
+        if rc:
+            return rc, outs
+    ctx.check(ctx.interpolate())
+    for sc, idx in fibonacci_closures(field, N, orc.root_of_unity(field, N)):
+        ctx.check(ctx.polys_lincomb(sc, idx))
+    rc, root = ctx.lde_commit(8, rng.nonzero(p), 6)
+    if rc:
+        return rc, outs
+    outs.append(root)
+    ctx.check(ctx.mix(rng.field(p)))
+    rounds = ctx.ceil_log2_k((N - 1) * 8 + 1)
+    rc, root = ctx.fri_begin(8, rounds)
+    if rc:
+        return rc, outs
+    outs.append(root)
+    for _ in range(1, rounds):
+        rc, B = ctx.fri_deep([rng.field(p) for _ in range(e)])
+        if rc:
+            return rc, outs
+        rc, root = ctx.fri_fold_commit([rng.field(p) for _ in range(e)])
+        if rc:
+            return rc, outs
+        outs.append((B.tolist(), root))
+    if read == "blocking":
+        rc, proof = ctx.fri_query([rng.next(), 5])
+        outs.append(proof)
+        return rc, outs
+    rc, _ = ctx.fri_query([rng.next(), 5], read=False)
+    if rc:
+        return rc, outs
+    n = ctx.fri_proof_size()
+    buf = ctx.pinned_alloc(n)          # (not freed here: a copy that never completes may still "own" it - the test's context frees nothing under it either)
+    rc = ctx.L.ms_fri_proof_read_async(ctx.h, C.c_void_p(buf))
+    if rc == 0:
+        rc = ctx.L.ms_fri_proof_wait(ctx.h)
+    if rc == 0:
+        outs.append(C.string_at(buf, n))
+    return rc, outs, buf
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_copy_engine_failures_fail_closed(monkeypatch, field):
+    """VERDICT r4 #6 / ADVICE r4: the boundary's engine copies under failure, on the emulation build's scripted engine (MS_EMU_SDMA; rt.hpp).
+      ok    - upload and read-back travel "on the engine" and the proof is the plain one; a prefetched trace (ms_trace_upload_async) is found, a prefetch of ANOTHER
+              trace is ignored, back-to-back proofs alternate the two device buffers;
+      fail  - the engine reports a failed copy (negative completion signal): both transfers are redone through the runtime's copy, same bytes, ms_io_engine says 0;
+      hang  - the read-back never completes: MS_ERR_HIP from ms_fri_proof_wait, then MS_ERR_STATE from EVERY entry point (nothing rewrites the blob or re-arms the
+              signal under the live copy), and ms_destroy returns; the same for an upload that never completes."""
+    import ctypes as C
+    import numpy as np
+    from common import fibonacci_trace_fast
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+    N = 64
+    trace = fibonacci_trace_fast(field, N)
+    other = fibonacci_trace_fast(field, N, secret_b=11)
+    mk = lambda: ms.Context(field, lib_path=EMU)
+    monkeypatch.delenv("MS_EMU_SDMA", raising=False)
+    plain = mk()
+    rc, want = _prove_raw(plain, field, trace)[:2]
+    rc2, want_other = _prove_raw(plain, field, other)[:2]
+    assert rc == 0 and rc2 == 0 and want != want_other
+    assert plain.io_runtime_path() == ""
+    plain.close()
+
+    def pinned_copy(ctx, t):
+        ptr = ctx.pinned_alloc(t.nbytes)
+        C.memmove(ptr, t.ctypes.data, t.nbytes)
+        return ptr
+
+    # ---- ok: engine copies, prefetch hit / miss, alternating buffers
+    monkeypatch.setenv("MS_EMU_SDMA", "ok")
+    ctx = mk()
+    pa, pb = pinned_copy(ctx, trace), pinned_copy(ctx, other)
+    r = _prove_raw(ctx, field, trace, upload=pa, read="async", prefetch_next=(pb, N, 3))
+    assert r[0] == 0 and r[1] == want and ctx.L.ms_io_engine(ctx.h) == 1 and "emulated" in ctx.io_runtime_path()
+    r = _prove_raw(ctx, field, other, upload=pb, read="async", prefetch_next=(pb, N, 3))       # the prefetched trace; then a prefetch the next commit does not name
+    assert r[0] == 0 and r[1] == want_other
+    r = _prove_raw(ctx, field, trace, upload=pa, read="async")                                 # (prefetched: `other`; committed: `trace`)
+    assert r[0] == 0 and r[1] == want
+    for _ in range(3):                                                                        # back-to-back, each prefetching its successor
+        r = _prove_raw(ctx, field, trace, upload=pa, read="async", prefetch_next=(pa, N, 3))
+        assert r[0] == 0 and r[1] == want
+    ctx.close()
+
+    # ---- fail: the engine reports failure, the runtime's copy delivers
+    monkeypatch.setenv("MS_EMU_SDMA", "fail")
+    ctx = mk()
+    pa = pinned_copy(ctx, trace)
+    r = _prove_raw(ctx, field, trace, upload=pa, read="async", prefetch_next=(pa, N, 3))
+    assert r[0] == 0 and r[1] == want and ctx.L.ms_io_engine(ctx.h) == 0
+    r = _prove_raw(ctx, field, trace, upload=pa, read="async")                                 # (the failed prefetch is redone by the commit)
+    assert r[0] == 0 and r[1] == want
+    ctx.close()
+
+    # ---- hang (read-back): poisoned context
+    monkeypatch.setenv("MS_EMU_SDMA", "hang")
+    monkeypatch.setenv("MS_UPLOAD", "hip")
+    ctx = mk()
+    r = _prove_raw(ctx, field, trace, read="async")
+    assert r[0] == ms.ERR_HIP and "poisoned" in ctx.last_error()
+    root = (C.c_uint8 * 32)()
+    t = np.ascontiguousarray(trace)
+    assert ctx.L.ms_trace_commit(ctx.h, t.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(N), C.c_size_t(3), C.c_size_t(6), root) == ms.ERR_STATE
+    assert ctx.L.ms_fri_query(ctx.h, (C.c_uint64 * 2)(3, 5), 2) == ms.ERR_STATE          # would rewrite the blob the engine is still reading
+    assert ctx.L.ms_fri_proof_wait(ctx.h) == ms.ERR_STATE and ctx.L.ms_fri_proof_read_async(ctx.h, C.c_void_p(r[2])) == ms.ERR_STATE
+    assert ctx.L.ms_interpolate(ctx.h) == ms.ERR_STATE and ctx.L.ms_synchronize(ctx.h) == ms.ERR_STATE
+    assert "poisoned" in ctx.last_error()
+    ctx.close()                                                                           # waits for the transfer (the scripted engine lets an unlimited wait return), then frees
+    monkeypatch.delenv("MS_UPLOAD")
+
+    # ---- hang (upload)
+    monkeypatch.setenv("MS_EMU_SDMA", "hang-upload")
+    ctx = mk()
+    pa = pinned_copy(ctx, trace)
+    rc, _ = ctx.trace_commit_ptr(pa, N, 3, 6)
+    assert rc == ms.ERR_HIP and "poisoned" in ctx.last_error()
+    assert ctx.trace_commit(trace, 6)[0] == ms.ERR_STATE
+    ctx.close()
+    ctx = mk()                                                                            # a prefetch that never completes surfaces at the commit that needs it
+    pa = pinned_copy(ctx, trace)
+    assert ctx.trace_upload_async(pa, N, 3) == 0
+    assert ctx.trace_commit_ptr(pa, N, 3, 6)[0] == ms.ERR_HIP and ctx.interpolate() == ms.ERR_STATE
+    ctx.close()

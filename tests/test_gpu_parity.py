@@ -319,7 +319,7 @@ def _oracle_threads():
 def test_config3_2p24_rows_bit_exact_vs_oracle(mk):
     """BASELINE.json configs[3] at FULL size on one GPU: Fibonacci AIR, Goldilocks, 2^24 trace rows, blowup 8 (L = 2^27, 27 FRI rounds,
     ~25 GiB resident): every commitment, DEEP value, FRI round and the ~1 GiB serialised FRI proof bit-exact against the CPU oracle
-    (OpenMP over its independent loops).  Minutes of host time; the log of the builder's run is profiles/r02_fullsize_parity.log."""
+    (OpenMP over its independent loops).  Minutes of host time."""
     import time
     orc.set_threads(_oracle_threads())
     t0 = time.time()

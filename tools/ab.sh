@@ -4,7 +4,7 @@
 #   bash tools/ab.sh OUTDIR PASSES "name1|ENV=V ..|bench args" "name2|..|.." ...
 # e.g. bash tools/ab.sh gpurun_out/ab_share 3 "share|MS_NTT_SHARE=1|--steps 40" "noshare|MS_NTT_SHARE=0|--steps 40"
 # A variant's third field is appended to `python3 bench.py --no-cpu-baseline --no-extras`; a field starting with "tool:" runs that command line instead.
-# (This replaces the one-off tools/r03_exp*.sh drivers of round 3; their logs under profiles/r03_* are the record of what they measured.)
+# (This replaces the one-off tools/r03_exp*.sh drivers of round 3; profiles/HISTORY.md is the record of what they measured.)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=$1; P=$2; shift 2
 mkdir -p $O

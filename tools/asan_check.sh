@@ -1,12 +1,12 @@
 #!/bin/bash
 # AddressSanitizer + UBSan over the kernel code and the host orchestration on the CPU (the GPU pool offers no sanitizer runs):
 # the kernel-emulation build (tests/emu, -DMS_EMU) executes every kernel phase thread by thread on malloc'ed "device" memory, so
-# out-of-bounds global/LDS indices, misaligned accesses and signed overflow in kernels and in ministark.cpp show up here.
+# out-of-bounds global/LDS indices, misaligned accesses and signed overflow in kernels and in the host units (csrc/*.cpp) show up here.
 #   bash tools/asan_check.sh        (≈ 2 min)
 set -e
 cd "$(dirname "$0")/.."
 OUT=${MS_EMU_LIB:-/tmp/libministark_emu_asan.so}
-g++ -O1 -g -std=c++17 -fPIC -shared -DMS_EMU -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-unknown-pragmas -o "$OUT" mini-stark_amd/csrc/ministark.cpp
+make -C tests/emu -j8 BUILD=/tmp/ms_emu_asan_obj EMUFLAGS="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer" libministark_emu.so LIBOUT="$OUT" > /dev/null
 export MS_EMU_LIB="$OUT" ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 python tools/asan_cases.py
 ( cd tests && python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29931 shard_worker.py 0 8 8 16 2>&1 | grep -E '^\{|ERROR|runtime error' )

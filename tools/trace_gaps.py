@@ -32,3 +32,8 @@ for i, g in enumerate(gaps):
         n = seg[i]["Kernel_Name"]; n = n.split("ms_kmain_coop<")[-1] if "ms_kmain_coop<" in n else n.split("ms_kmain<")[-1]
         bg[n.split(">(")[0][:50]] += g
 print("host round trips by preceding kernel (us):", {k: round(v / 1e3, 1) for k, v in bg.most_common(8)})
+if "--dump" in sys.argv:   # every launch of the proof in order: start offset, duration, gap behind it (us), kernel - the per-round picture of the latency path
+    print("\n#   t_us    dur_us  gap_us  kernel")
+    for i, r in enumerate(seg):
+        n = r["Kernel_Name"]; n = n.split("ms_kmain_coop<")[-1] if "ms_kmain_coop<" in n else n.split("ms_kmain<")[-1]
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} {gaps[i] / 1e3:7.1f}  {n.split('>(')[0][:70]}  grid={r.get('Grid_Size_X', '?')}")
