@@ -155,7 +155,7 @@ class Lanes:
     host-mirror Stark each.  io=False: traces resident in HBM, FRI proofs left in HBM.  io=True: every proof uploads its trace
     from page-locked host memory and reads the FRI proof back into page-locked host memory."""
 
-    def __init__(self, field, log_rows, blowup, inflight, device_index, dev, seed0=2, io=False, lib=None, io_mode="async", upload=None):
+    def __init__(self, field, log_rows, blowup, inflight, device_index, dev, seed0=2, io=False, lib=None, io_mode="async", upload=None, flags=None, prefetch=True):
         import numpy as np
         import torch
         import mini_stark_amd as ms
@@ -167,7 +167,9 @@ class Lanes:
         # rounds at the same time, then all in the LDE hashing - and a 20-step run measured 246 proofs/s that way against 256 with the stagger (r03; profiles/HISTORY.md)
         self.stagger_ms = float(os.environ.get("MS_BENCH_STAGGER_MS", "1"))
         steps = (1 << log_rows) - 1  # "2^k trace rows" => steps = 2^k - 1 (quirk Q3)
-        self.ctxs = [ms.Context(field, device=device_index, lib_path=lib) for _ in range(inflight)]
+        self.prefetch = prefetch   # io: every proof names the next proof's trace (here: the lane's own, again), whose upload then overlaps the proof (ms_trace_upload_async)
+        kw = {} if flags is None else {"flags": flags}
+        self.ctxs = [ms.Context(field, device=device_index, lib_path=lib, **kw) for _ in range(inflight)]
         self.tts = [fibonacci_air(c, steps, secret_b=seed0 + i) for i, c in enumerate(self.ctxs)]
         self.cfg = StarkConfig(self.ctxs[0], 20, blowup, steps, self.tts[0].constrain_number())
         self.starks = [HostStark(c, 20, blowup, steps, self.tts[0].constrain_number()) for c in self.ctxs]
@@ -192,6 +194,8 @@ class Lanes:
             # complete when prove returns, and EVERY proof is touched on the host (one word per page) before its slot is reused two proofs later.
             # io, mode "async": the read-back of proof k (copy stream) overlaps the first stages of proof k + 1; proof k is sampled from the mirror's OTHER
             # slot after prove k + 1 returned (two proof slots: ADVICE r2), the last one after the final wait.
+            if self.upload and self.prefetch and k + 1 < n:
+                self.starks[i].next_trace(self.tts[i].data.ctypes.data, self.tts[i].length, self.tts[i].width)
             self.ctxs[i].check(self.starks[i].prove_raw(self.tts[i], trace_device_ptr=ptr, read_fri_proof=self.io_mode if self.io else False))
             if self.io and self.io_mode == "into":
                 self.samples[i].add(self.starks[i].blob_sample(0))
@@ -368,7 +372,7 @@ def profile_is_current(round_tag):
 
 def load_sq_profile():
     """VALU wave-instructions per thread per (kernel, grid) from this round's rocprofv3 SQ-counter pass (tools/process_profiles.py)."""
-    for name in ("r04_sq_counters_top_kernels.csv", "r03_sq_counters_top_kernels.csv", "r02_sq_counters_top_kernels.csv", "r01_sq_counters_top_kernels.csv"):
+    for name in ("r05_sq_counters_top_kernels.csv", "r04_sq_counters_top_kernels.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             rows = list(csv.DictReader(open(path)))
@@ -514,7 +518,7 @@ def main():
         avg_ms = k["ms"] / max(1, k["launches"])
         achieved = (k["alg_bytes"] / max(1, k["launches"])) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src, pmc_variants = None, None, {}
-        for name in ("r04_pmc_ntt_pass.json", "r03_pmc_ntt_pass.json", "r02_pmc_ntt_pass.json", "pmc_ntt_pass.json"):
+        for name in ("r05_pmc_ntt_pass.json", "r04_pmc_ntt_pass.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -598,6 +602,30 @@ def main():
                                     "instr_profile_taken_from_this_kernel_source": profile_is_current(sq_name[:3]),
                                     "times": "live: HIP events of this run, one proof alone (small tree levels are latency-bound, which lowers the class average)", "kernels": rv}
 
+        # ---- what actually bounds the proof: the kernel class with the largest share of a proof's kernel time, priced on the roofline of ITS class.
+        # `roofline` above stays the NTT object the metric names (NTT GB/s against HBM); this is the one a reader should take for "how close to the hardware is the prover"
+        classes = {n: v["ms"] for n, v in prof.items() if isinstance(v, dict) and v.get("launches")}
+        dom = max(classes, key=classes.get) if classes else None
+        if dom:
+            rd = {"kernel_class": dom, "share_of_kernel_time": classes[dom] / tot, "ms_per_proof": classes[dom], "launches_per_proof": prof[dom]["launches"],
+                  "sha256_classes_share_of_kernel_time": sha / tot,
+                  "kernels": {"leaf_hash": "msmerkle::LeafHashKernel<F, E> + PadOnlyBlockKernel (csrc/merkle.hpp)", "inner_hash": "msmerkle::InnerHashKernelT<2> + InnerSubtreeKernel (csrc/merkle.hpp)"}.get(dom, dom)}
+            rvd = out.get("roofline_valu", {}).get("kernels", {}).get(dom)
+            if rvd:   # a SHA-256 class: 32-bit VALU issue is the roofline
+                rv_all = out["roofline_valu"]
+                rd.update({"bound": "valu_issue", "unit": "wave-instr/s", "achieved": rvd["achieved_wave_instr_per_s"], "peak": rv_all["peak_guide"], "frac": rvd["frac_of_guide_peak"],
+                           "peak_source": "MI355X_MICROARCH.md: a wave64 VALU instruction occupies a SIMD-32 for 2 cycles; 1024 SIMDs x 2.4 GHz / 2",
+                           "valu_wave_instr_per_proof": rvd["valu_wave_instr_per_proof"], "instr_source": rv_all["instr_source"],
+                           "instr_profile_taken_from_this_kernel_source": rv_all["instr_profile_taken_from_this_kernel_source"],
+                           "measured_ceiling": rv_all["peak_sha_lab"], "frac_of_measured_ceiling": rvd["frac_of_sha_lab_rate"], "measured_ceiling_source": rv_all["peak_sha_lab_basis"],
+                           "largest_launch": rv_all["whole_proof"].get("largest_leaf_launch") if dom == "leaf_hash" else None,
+                           "whole_proof_at_headline_rate": {k: rv_all["whole_proof"][k] for k in ("achieved_wave_instr_per_s", "frac_of_guide_peak", "frac_of_sha_lab_rate") if k in rv_all["whole_proof"]},
+                           "times": "live (HIP events of this run, one proof alone); instruction counts: constants from the committed rocprofv3 SQ_INSTS_VALU pass"})
+            else:
+                rd.update({"bound": "hbm", "unit": "GB/s", "achieved": prof[dom]["alg_bytes"] / (classes[dom] * 1e-3) / 1e9 if prof[dom].get("alg_bytes") else None, "peak": HBM_PEAK_GBS})
+                rd["frac"] = rd["achieved"] / HBM_PEAK_GBS if rd["achieved"] else None
+            out["roofline_dominant"] = rd
+
         if world == 1 and not args.no_extras and args.log_rows == 20 and args.field == 0:
             lanes.close()
             lanes = None
@@ -609,12 +637,12 @@ def main():
                 except Exception as e:  # noqa: BLE001 - an extra leg must not take the headline down
                     extra[name] = {"error": f"{type(e).__name__}: {e}"}
 
-            def proofs_leg(field, log_rows, steps, warmup, inflight=None, io=False, io_mode="async", copies=None):
+            def proofs_leg(field, log_rows, steps, warmup, inflight=None, io=False, io_mode="async", copies=None, flags=None):
                 infl = inflight or default_inflight(log_rows)
                 if copies:   # "hip": the boundary's bulk copies by the HIP runtime (hipMemcpyAsync) instead of the SDMA engines - read at ms_create
                     os.environ["MS_READBACK"], os.environ["MS_UPLOAD"] = copies, copies
                 try:
-                    ln = Lanes(field, log_rows, args.blowup, infl, local_rank, dev, io=io, io_mode=io_mode)
+                    ln = Lanes(field, log_rows, args.blowup, infl, local_rank, dev, io=io, io_mode=io_mode, flags=flags)
                 finally:
                     if copies:
                         del os.environ["MS_READBACK"], os.environ["MS_UPLOAD"]
@@ -658,7 +686,11 @@ def main():
             leg("value_with_io_kernels_write_host", lambda: dict(proofs_leg(0, 20, 10, 2, io=True, io_mode="into"), workload="the same with ms_fri_query_into: the query-phase kernels store the FRI proof straight into "
                                               "page-locked host memory (no copy).  Measured r03: SLOWER (the 64 MiB cross PCIe as stores of kernels whose waves hold their CUs meanwhile; coherent or non-coherent "
                                               "pinned memory alike) - kept as an API for device-memory destinations, not used as the read-back path"))
-            leg("single_proof", lambda: dict(proofs_leg(0, 20, 30, 4, inflight=1), workload="configs[1] with ONE proof in flight (latency configuration): 1 / value = the time of one Stark::prove"))
+            import mini_stark_amd as _ms
+            leg("single_proof", lambda: dict(proofs_leg(0, 20, 30, 4, inflight=1, flags=_ms.FLAG_ZERO_DISPLAY_EMPTY | _ms.FLAG_LATENCY),
+                                             workload="configs[1] with ONE proof in flight, context created with MS_FLAG_LATENCY (the latency configuration: a FRI round's coefficient side on a side "
+                                                      "stream beside its evaluation side): 1 / value = the time of one Stark::prove"))
+            leg("single_proof_default_flags", lambda: dict(proofs_leg(0, 20, 30, 4, inflight=1), workload="the same without MS_FLAG_LATENCY (the throughput configuration, one lane)"))
 
             def wide_air():
                 # BASELINE configs[4] on one GPU: 64 trace columns + 64 transition polynomials (c = 128), Goldilocks, 2^22 rows, blowup 8; linear transitions

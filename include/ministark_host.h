@@ -38,6 +38,9 @@ int msh_stark_config(const msh_stark* h, uint64_t* rounds, uint64_t* constrain_q
 /* Stark::prove (starks.rs:59-169): trace from host memory or already in HBM; transitions as lincombs of trace polynomials */
 int msh_stark_prove(msh_stark* h, const uint64_t* trace_host, const void* trace_dev, size_t N, size_t w, int ntrans, const int* tr_k,
                     const uint64_t* tr_scalars, const int* tr_idx, int read_fri_proof);
+/* A pipelined caller names the page-locked (ms_pinned_alloc) row-major trace of the proof AFTER the next msh_stark_prove: that call hands it to
+ * ms_trace_upload_async right behind its own trace commitment, so the upload overlaps the proof (one-shot: name it again before every prove). */
+void msh_stark_next_trace(msh_stark* h, const uint64_t* trace_host, size_t N, size_t w);
 size_t msh_proof_arthur(const msh_stark* h, uint8_t* out, size_t cap);
 int msh_proof_commits(const msh_stark* h, uint8_t* trace_commit, uint8_t* lde_commit);
 size_t msh_proof_evals(const msh_stark* h, uint64_t* out, size_t cap_elems);

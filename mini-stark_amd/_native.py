@@ -14,6 +14,7 @@ import numpy as np
 GOLDILOCKS, BABYBEAR = 0, 1
 FLAG_ZERO_DISPLAY_EMPTY = 1
 FLAG_TRACE_MONT64 = 2
+FLAG_LATENCY = 4   # the context proves alone on its GPU: independent chains of a stage on two streams (costs throughput with several contexts in flight)
 OK, ERR_SHAPE, ERR_LEAF_NOT_FOUND, ERR_OUT_OF_RANGE, ERR_STATE, ERR_ARG, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

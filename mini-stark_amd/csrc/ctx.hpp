@@ -184,7 +184,7 @@ template <class F> struct Ctx : CtxBase {
 
   // ---- optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
   enum { K_NTT_PASS, K_SCALE_POW, K_LEAF_HASH, K_INNER_HASH, K_TRANSPOSE, K_IO, K_LINCOMB, K_MIX, K_EVAL, K_EVAL_REDUCE, K_FOLD,
-         K_SUFFIX_HORNER, K_DEGREE, K_FIND_FIRST, K_PATH, K_QUERY_POINTS, K_COUNT };
+         K_SUFFIX_HORNER, K_DEGREE, K_FIND_FIRST, K_PATH, K_QUERY_POINTS, K_FRI_TAIL, K_COUNT };
   struct ProfRec { int kid, sub; msrt::Event* a; msrt::Event* b; double bytes; bool part; };
   // sharded proofs: launches inside a PartScope work on this rank's PART of the proof (1 / world of it); everything else is replicated on every rank.
   // ms_profile_end reports both sums: the replicated one bounds the strong scaling (bench.py: sharded.replicated_ms_estimate)
@@ -375,6 +375,8 @@ template <class F> struct Ctx : CtxBase {
     for (msrt::Event* e : ev_hash) msrt::event_destroy(e);
     for (msrt::Event* e : ev_xchg) msrt::event_destroy(e);
     if (comm_stream) msrt::stream_destroy(comm_stream);
+    if (side_stream) { msrt::sync(side_stream); msrt::stream_destroy(side_stream); }
+    if (ev_side) msrt::event_destroy(ev_side);
     if (ev_blob) msrt::event_destroy(ev_blob);
     if (ev_copy) msrt::event_destroy(ev_copy);
     if (copy_stream) msrt::stream_destroy(copy_stream);
@@ -522,6 +524,16 @@ template <class F> struct Ctx : CtxBase {
   int fold_dist(Round* pr, Round* nr, const XE& a, size_t* nq_coef_out);
   // fri.rs:96-109
   int fri_fold_commit(const u64* alpha, u8* root) override;
+  // MS_FRI_TAIL_MAX: rounds folding a domain of at most this many points run as ONE launch (fri_tail.hpp; 0: never).  Same-box A/B: DESIGN.md
+  size_t fri_tail_max = (size_t)1 << 13;
+  // MS_FLAG_LATENCY (r05): the coefficient side of a round's ms_fri_fold_commit (fold, DEEP quotient scan, trimmed length: ~55 us of small launches) on a SIDE stream
+  // while the evaluation side (pointwise codeword, leaf hashing, tree) runs on the context's stream - the two are independent (the codeword never reads the
+  // quotient); the launch that forwards root and length word to the host waits for the side stream's event.  The fused tail rounds do the same inside one kernel.
+  int fri_overlap = 0;   // MS_FLAG_LATENCY at ms_create (MS_FRI_OVERLAP=0/1 overrides: A/B)
+  msrt::Stream* side_stream = nullptr; msrt::Event* ev_side = nullptr; bool side_pending = false;
+  struct StreamScope { Ctx* c; msrt::Stream* keep; StreamScope(Ctx* c_, msrt::Stream* s) : c(c_), keep(c_->stream) { c->stream = s; } ~StreamScope() { c->stream = keep; } };
+  int join_side() { if (side_pending) { side_pending = false; CK(msrt::stream_wait_event(stream, ev_side)); } return 0; }   // the context's stream goes on only behind the side stream's work
+  int fri_tail_round(Round* pr, Round* nr, const XE& a, bool* done);
   int fri_round_info(int r, u64* ncoef, u64* D) override;
   int fri_round_poly_read(int r, u64* out) override;
   int fri_round_codeword_read(int r, u64* out) override;

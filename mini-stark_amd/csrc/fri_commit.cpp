@@ -1,6 +1,7 @@
 // fri_commit.cpp — the FRI commit phase (fri.rs:64-113, 301-377): round commitments, even(z) / odd(z), fold + DEEP quotient (replicated and by coefficient range),
 // and the suffix-Horner job planning the query phase shares.
 #include "ctx.hpp"
+#include "fri_tail.hpp"
 
 namespace msctx {
 
@@ -49,6 +50,7 @@ int Ctx<F>::round_commit(Round* r, size_t ncoef_in, int nonzero_limbs, const Rou
       return 0;
     }
   }
+  RQ(join_side());   // from here on the round polynomial itself is transformed: the side stream's quotient must be complete
   if (shardable(r->D / 2)) {  // leaf group j = codeword elements 2j, 2j+1: rank k owns the groups k (mod world) = two cosets of size m
     const size_t m = r->D / (2 * (size_t)sh_world);
     r->m = m;
@@ -106,7 +108,11 @@ int Ctx<F>::fri_begin(size_t blowup_, size_t nrounds, u8* root0) {
   if (!root0 || nrounds < 1 || !blowup_) return fail(MS_ERR_ARG, "fri_begin");
   nrounds_done = 0; have_deep = false; blob_size = 0;
   fri_rounds = nrounds; fri_blowup = blowup_;
-  if (d_deg.p) CK(msrt::memset_dev(d_deg.p, 0, 256, stream));   // the self-clearing degree word of fri_fold_commit: zero again even if an earlier proof was abandoned mid-round
+  // the self-clearing length word (and completion counter) of ms_fri_fold_commit: allocated and zeroed HERE, behind this stage's stream synchronisation - zeroing it
+  // lazily in the first ms_fri_fold_commit raced with the side stream's length scan (r05: first proof of a context, eight lanes in flight) - and zero again even if
+  // an earlier proof was abandoned mid-round
+  if (!d_deg.p && d_deg.ensure(256)) return fail(MS_ERR_NOMEM, "degree word");
+  CK(msrt::memset_dev(d_deg.p, 0, 256, stream));
   Round* r = round_slot(0);
   const size_t VL = validity_len;   // N (ms_mix) or 2N (ms_mix_cubic)
   r->cap = VL;
@@ -303,6 +309,62 @@ int Ctx<F>::fold_dist(Round* pr, Round* nr, const XE& a, size_t* nq_coef_out) {
   return 0;
 }
 
+// fri.rs:96-109 for a round of the latency-bound tail, as ONE launch (fri_tail.hpp): fold, DEEP quotient, trimmed length, pointwise codeword, leaf digests, every tree
+// level, root and length word into page-locked memory.  *done = false: the round does not qualify (the caller takes the launch-per-step path).
+template <class F>
+int Ctx<F>::fri_tail_round(Round* pr, Round* nr, const XE& a, bool* done) {
+  *done = false;
+  const size_t n = pr->ncoef, m = (n + 1) / 2, Dn = nr->D, M = Dn / 2;
+  bool z_outside_base = false;
+  for (int l = 1; l < E; l++) z_outside_base = z_outside_base || cur_z.c[l] != 0;
+  // replicated rounds only (a sharded proof's tail is replicated on every rank); the pointwise codeword needs y - z != 0 on the base-field domain; one scan block
+  if (!fri_tail_max || pr->D > fri_tail_max || pr->dist || pr->ts.sharded || shardable(M) || !fri_pointwise || !z_outside_base || m > (size_t)mspoly::SH_BS || M < 1) return 0;
+  typedef msfri::FriTailKernel<F, E> TK;
+  if (M > (size_t)TK::WG_GROUPS << msmerkle::InnerSubtreeKernel::MAX_LEVELS) return 0;
+  if (ctz64(Dn) > F::TWO_ADICITY) return fail(MS_ERR_SHAPE, "FRI domain larger than the field's two-adicity");
+  RQ(tree_shape(Dn, 2, 2, &nr->ts));
+  nr->m = 0;
+  if (nr->poly.ensure(nr->cap * E * sizeof(T)) || d_folded.ensure((m + 1) * E * sizeof(T)) || nr->cw.ensure(Dn * E * sizeof(T)) || nr->nodes.ensure(nr->ts.nodes * 32) ||
+      d_sh.ensure(sh_scratch_elems(m) * sizeof(T)))
+    return fail(MS_ERR_NOMEM, "fused FRI round");
+  Plan* pl;
+  RQ(get_plan(ctz64(pr->D), 0, false, &pl));   // w_D^e tables of the previous domain
+  typename TK::Params tp;
+  memset(&tp, 0, sizeof tp);
+  // ---- coefficient side
+  tp.do_coef = m >= 2 ? 1 : 0;
+  tp.fold = typename TK::FoldK::Params{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a};
+  if (tp.do_coef) {
+    SHPlan sp = sh_plan(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), false, nr->cap, 0, 1, nullptr, d_sh.as<T>());
+    if (sp.nl != 1) return fail(MS_ERR_STATE, "fused FRI round: scan of more than one block");
+    tp.scan.jobs = nullptr; tp.scan.inline_job = sp.fin[0]; tp.scan.final_mode = 1;
+  }
+  unsigned long long* dres = d_deg.as<unsigned long long>();       // the length word: zero between rounds (the forwarding thread clears it)
+  tp.deg = typename TK::DegK::Params{nr->poly.template as<T>(), nr->cap, m >= 2 ? m - 1 : 0, dres, 0};
+  // ---- evaluation side
+  const size_t per = M < (size_t)TK::WG_GROUPS ? M : (size_t)TK::WG_GROUPS, G = M / per;
+  tp.G = (u32)G;
+  const XE c = e_add<F, E>(cur_B[0], e_mul<F>(cur_B[1], a));         // B(alpha), fri.rs:99
+  tp.eval.src = pr->cw.template as<T>(); tp.eval.src_limb_stride = pr->D; tp.eval.dst = nr->cw.template as<T>(); tp.eval.dst_limb_stride = Dn;
+  tp.eval.m_out = Dn; tp.eval.log_m = (u32)ctz64(Dn); tp.eval.groups = 1; tp.eval.shard_W = 0; tp.eval.shard_k = 0;
+  tp.eval.tw_lo = pl->tw_lo.template as<T>(); tp.eval.tw_hi = pl->tw_hi.template as<T>(); tp.eval.lo_bits = (u32)pl->lo_bits; tp.eval.log_D = (u32)ctz64(pr->D);
+  tp.eval.alpha = a; tp.eval.c2 = e_add<F, E>(c, c); tp.eval.z = cur_z; tp.eval.inv2 = f_inv<F>(F::from_u64(2));
+  tp.leaf.base = nr->cw.template as<T>(); tp.leaf.col_stride = 0; tp.leaf.row_stride = 1; tp.leaf.limb_stride = Dn; tp.leaf.width = 1; tp.leaf.lpn = 2;
+  tp.leaf.zero_as_empty = zae; tp.leaf.ngroups = M; tp.leaf.nodes = nr->nodes.template as<u32>();   // (ovf* = null: pad-only blocks in place; no runs, no virtual columns)
+  u32 nl = 0; while (((size_t)1 << nl) < per) nl++;
+  tp.sub.nodes = nr->nodes.template as<u32>(); tp.sub.child_off = 0; tp.sub.nchildren = M; tp.sub.ic = 2; tp.sub.nlevels = nl;
+  u32 tl = 0; while (((size_t)1 << tl) < G) tl++;
+  tp.top.nodes = nr->nodes.template as<u32>(); tp.top.child_off = 2 * M - 2 * G; tp.top.nchildren = G; tp.top.ic = 2; tp.top.nlevels = tl;
+  tp.top.host_root = host_root(); tp.top.aux_src = dres; tp.top.aux_dst = reinterpret_cast<unsigned long long*>(pinned);
+  tp.root_index = nr->ts.nodes - 1;
+  tp.done = reinterpret_cast<u32*>(d_deg.as<u8>() + 128);            // (same zeroed line as the length word; the last workgroup leaves it zero)
+  next_bytes = (double)Dn * E * sizeof(T) * 3 + (double)M * 96;
+  CK(run_coop<TK>(K_FRI_TAIL, (unsigned)(G + 1), TK::THREADS, TK::lds_bytes(), tp));
+  root_on_host = true; aux_on_host = true;
+  *done = true;
+  return 0;
+}
+
 // fri.rs:96-109
 template <class F>
 int Ctx<F>::fri_fold_commit(const u64* alpha, u8* root) {
@@ -317,10 +379,23 @@ int Ctx<F>::fri_fold_commit(const u64* alpha, u8* root) {
   nr->D = pr->D / 2;  // fri.rs:104, 374-376
   nr->dist = false; nr->local_store = false; nr->S = 0;
   size_t nq_coef = 0;
+  bool fused = false, side = false;
+  RQ(fri_tail_round(pr, nr, a, &fused));
+  if (fused) {   // one launch did the whole round; the length word and the root are in page-locked memory behind the stream synchronisation
+    CK(msrt::sync(stream));
+    nr->ncoef = (size_t)(*reinterpret_cast<unsigned long long*>(pinned));
+    memcpy(root, reinterpret_cast<const u8*>(host_root()), 32);
+    nrounds_done++; have_deep = false;
+    return MS_OK;
+  }
   if (pr->dist) RQ(fold_dist(pr, nr, a, &nq_coef));
   else {
   if (nr->poly.ensure(nr->cap * E * sizeof(T)) || d_folded.ensure((m + 1) * E * sizeof(T))) return fail(MS_ERR_NOMEM, "fold");
   if (m >= 2) {
+    // the coefficient side on the side stream (every stage ends with a synchronisation of the context's stream behind a join: the side stream starts on finished data)
+    side = fri_overlap && !prof_on;   // (the per-kernel profile times launches one behind the other on ONE stream)
+    if (side && !side_stream) { CK(msrt::stream_create(&side_stream)); CK(msrt::event_create(&ev_side)); }
+    StreamScope on_side(this, side ? side_stream : stream);
     typename mspoly::FoldKernel<F, E>::Params fp{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a};  // fri.rs:361-372
     CK(run<mspoly::FoldKernel<F, E>>(K_FOLD, grid1(m, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
     // (folded - B(alpha)) / (x - z): quotient coefficients are H_1.. of the suffix Horner in z (fri.rs:99-101)
@@ -331,8 +406,7 @@ int Ctx<F>::fri_fold_commit(const u64* alpha, u8* root) {
   // the degree scan runs BEFORE the commitment and the tree's final launch forwards its 8-byte result, with the root, into page-locked host memory:
   // no copy launch in front of the round's one stream synchronisation (r03; the trace showed a 4 us copyBuffer kernel + its launch gap per round)
   // (the word lives in d_deg, zeroed once: the forwarding thread clears it again - the pool of zero_alloc may be wiped while the tree is being built)
-  if (!d_deg.p) { if (d_deg.ensure(256)) return fail(MS_ERR_NOMEM, "degree word"); CK(msrt::memset_dev(d_deg.p, 0, 256, stream)); }
-  unsigned long long* dres = d_deg.as<unsigned long long>();
+  unsigned long long* dres = d_deg.as<unsigned long long>();   // (zeroed by ms_fri_begin)
   if (nr->dist) {   // this rank's part reports the GLOBAL trimmed length; the maximum over the ranks comes back with the subtree roots (finish_sharded_tree)
     const size_t lc = lcount(nr, nq_coef);
     if (lc) {
@@ -342,11 +416,14 @@ int Ctx<F>::fri_fold_commit(const u64* alpha, u8* root) {
     }
     shard_aux = dres;
   } else if (nq_coef) {
+    StreamScope on_side(this, side ? side_stream : stream);
     typename mspoly::DegreeKernel<F, E>::Params dp{nr->poly.template as<T>(), nr->cap, nq_coef, dres, 0};
     CK(run<mspoly::DegreeKernel<F, E>>(K_DEGREE, grid1(nq_coef, mspoly::THREADS), 1, mspoly::THREADS, 0, dp));
   }
+  if (side) { CK(msrt::event_record(ev_side, side_stream)); side_pending = true; }
   pending_aux = dres; aux_on_host = false;
   { auto clear = scope_exit([this] { pending_aux = nullptr; shard_aux = nullptr; });   // (also on an error exit: neither word may ride on the NEXT commitment's launches - ADVICE r4)
+    auto join = scope_exit([this] { if (side_pending) { side_pending = false; msrt::stream_wait_event(stream, ev_side); } });   // whatever path the commitment took (or left on): the context's stream ends behind the side stream
     RQ(round_commit(nr, nq_coef, E, pr, &a)); }
   if (!aux_on_host) { CK(msrt::d2h(pinned, dres, 8, stream)); CK(msrt::memset_dev(dres, 0, 8, stream)); }
   if (!root_on_host) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, nr->nodes.template as<u8>() + (nr->ts.local_nodes - 1) * 32, 32, stream));
@@ -393,6 +470,7 @@ int Ctx<F>::fri_round_codeword_read(int r, u64* out) {
   template int Ctx<FF>::suffix_horner(const Ctx<FF>::T* in, size_t in_limb_stride, size_t in_off, size_t in_stride, size_t m, const Ctx<FF>::XE& z, Ctx<FF>::T* out, size_t out_limb_stride, size_t out_off, size_t out_stride, Ctx<FF>::T* h0); \
   template int Ctx<FF>::gather_poly(const Ctx<FF>::T* local, size_t S, size_t count, Ctx<FF>::T* dst, size_t dst_stride); \
   template int Ctx<FF>::fold_dist(Ctx<FF>::Round* pr, Ctx<FF>::Round* nr, const Ctx<FF>::XE& a, size_t* nq_coef_out); \
+  template int Ctx<FF>::fri_tail_round(Ctx<FF>::Round* pr, Ctx<FF>::Round* nr, const Ctx<FF>::XE& a, bool* done); \
   template int Ctx<FF>::fri_fold_commit(const u64* alpha, u8* root); \
   template int Ctx<FF>::fri_round_info(int r, u64* ncoef, u64* D); \
   template int Ctx<FF>::fri_round_poly_read(int r, u64* out); \

@@ -378,7 +378,7 @@ template <class F, int E, bool LAZY = false> struct LeafHashKernel {
     u32 width, lpn; int zero_as_empty;
     size_t ngroups;
     u32* nodes;  // 8 words per digest, standard byte order in memory
-    u32* ovf_count; u32* ovf; u32 ovf_cap;  // deferred pad-only blocks: OVF_LISTS counters, and lists of ovf_cap entries of OVF_WORDS words (group, message bits)
+    u32* ovf_count; u32* ovf; u32 ovf_cap;  // deferred pad-only blocks: OVF_LISTS counters, and lists of ovf_cap entries of OVF_WORDS words (group, message bits); ovf == nullptr: no lists, such blocks are compressed in place
     // run_len != 0: the launch hashes `ngroups` groups that are RUNS of run_len consecutive groups, run_stride apart, from g_first on (one slice of
     // every peer's chunk of a sharded commitment: its digests can travel while the next slice is hashed)
     size_t g_first; u32 run_len, run_stride;
@@ -428,6 +428,14 @@ template <class F, int E, bool LAZY = false> struct LeafHashKernel {
       const int st = s.drain(j >= nlimbs, msg_bytes);  // the only compression site
       if constexpr (LAZY) { if (j >= nlimbs && st != Stream::MORE) { deferred = st == Stream::DEFER; break; } }
       else deferred = st == Stream::DEFER;
+    }
+    if (deferred && !p.ovf) {   // no deferred-block lists (the fused FRI round, fri_tail.hpp: a launch of a few waves has nothing to compact): the pad-only block right here
+      u32 w[16];
+#pragma unroll
+      for (int i = 0; i < 15; i++) w[i] = 0;
+      w[15] = msg_bytes * 8u;
+      s.h.compress(w);
+      deferred = false;
     }
     const u32 list = (u32)bx % (u32)OVF_LISTS;
     const u32 slot = msrt::wave_alloc_slot(p.ovf_count + list, deferred);

@@ -74,6 +74,7 @@ int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_lev
       u32 nl = 0; for (size_t m = nchildren; m > 1 && nl < (u32)SK::MAX_LEVELS; m >>= 1) nl++;
       const size_t left = nchildren >> nl;
       if (final_levels && left == 1) {
+        RQ(join_side());   // this launch forwards the length word the side stream's scan produces
         ip.host_root = host_root(); root_on_host = true;
         if (pending_aux) { ip.aux_src = pending_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
       }
@@ -84,6 +85,7 @@ int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_lev
       continue;
     }
     if (final_levels && (nparents == 1 || nparents <= (size_t)tree_top_parents)) {
+      RQ(join_side());
       ip.host_root = host_root(); root_on_host = true;
       if (pending_aux) { ip.aux_src = pending_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
     }

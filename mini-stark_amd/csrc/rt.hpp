@@ -136,6 +136,8 @@ struct FiberBlock {
   }
 };
 inline void wg_barrier() { FiberBlock::active()->yield(); }
+inline void wg_barrier_global() { FiberBlock::active()->yield(); }   // (the emulated workgroup's "global" memory is plain host memory: always coherent)
+inline void fence_device() {}
 inline int wave_uniform(int v) { return v; }
 // value of lane (lane ^ mask) of the caller's 64-lane wave; every thread of the workgroup must call it (like __shfl_xor under full exec)
 inline unsigned long long wave_shfl_xor(unsigned long long v, int mask) {
@@ -469,6 +471,11 @@ inline int launch_coop(Stream* s, unsigned gx, unsigned gy, int threads, size_t 
 // Global data written before the barrier is NOT made visible by it (these kernels never hand global data between waves).
 
 MS_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... and the barrier that DOES hand global data from wave to wave of a workgroup (fused multi-step kernels: one step's stores are the next step's loads)
+MS_DEV void wg_barrier_global() { __syncthreads(); }
+// device-scope release / acquire fence: global stores of this thread before it are visible to every workgroup of the device that synchronises with it through an
+// atomic behind it (the "last workgroup finishes the job" hand-over of the fused FRI round, fri_tail.hpp): L2 write-back / invalidate across the XCDs
+MS_DEV void fence_device() { __threadfence(); }
 MS_DEV unsigned long long wave_shfl_xor(unsigned long long v, int mask) { return __shfl_xor(v, mask, 64); }
 // a value every lane of the wave holds alike, moved to a scalar register (so that branches on it are scalar branches)
 MS_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -7,7 +7,7 @@ namespace msctx {
 template <class F>
 int Ctx<F>::profile_end(char* out, size_t cap) {
   static const char* names[K_COUNT] = {"ntt_pass", "scale_pow", "leaf_hash", "inner_hash", "transpose_in", "io_copy", "lincomb", "mix", "eval", "eval_reduce",
-                                       "fold", "suffix_horner", "degree", "find_first", "merkle_path", "query_points"};
+                                       "fold", "suffix_horner", "degree", "find_first", "merkle_path", "query_points", "fri_tail"};
   msrt::sync(stream);
   double ms[K_COUNT] = {0}, by[K_COUNT] = {0}, ms_part = 0, ms_repl = 0, repl_by[K_COUNT] = {0}; unsigned long long cnt[K_COUNT] = {0};
   std::map<int, double> sub_ms, sub_by; std::map<int, unsigned long long> sub_cnt;
@@ -92,7 +92,7 @@ int Ctx<F>::ensure_polys(size_t count) {
 
 template <class F>
 int Ctx<F>::init(int dev, u32 flags) {
-  device = dev; zae = (flags & MS_FLAG_ZERO_DISPLAY_EMPTY) ? 1 : 0; trace_mont = (flags & MS_FLAG_TRACE_MONT64) ? 1 : 0;
+  device = dev; zae = (flags & MS_FLAG_ZERO_DISPLAY_EMPTY) ? 1 : 0; trace_mont = (flags & MS_FLAG_TRACE_MONT64) ? 1 : 0; fri_overlap = (flags & MS_FLAG_LATENCY) ? 1 : 0;
   if (const char* e = getenv("MS_NTT_KMAX")) { int v = atoi(e); if (v >= 5 && v <= msntt::MAX_LOG_R) ntt_kmax = v; }
   if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
   if (const char* e = getenv("MS_NTT_V2")) ntt_v2 = atoi(e);
@@ -105,6 +105,8 @@ int Ctx<F>::init(int dev, u32 flags) {
   if (const char* e = getenv("MS_LDE_VIRTUAL")) lde_virtual = atoi(e);
   if (const char* e = getenv("MS_FRI_POINTWISE")) fri_pointwise = atoi(e);
   if (const char* e = getenv("MS_FOLD_SMALL_MAX")) fold_small_max = (size_t)atol(e);
+  if (const char* e = getenv("MS_FRI_TAIL_MAX")) fri_tail_max = (size_t)atol(e);
+  if (const char* e = getenv("MS_FRI_OVERLAP")) fri_overlap = atoi(e);
   if (const char* e = getenv("MS_EVAL_SMALL_MAX")) eval_small_max = (size_t)atol(e);
   if (const char* e = getenv("MS_TREE_SUBTREE_PARENTS")) subtree_parents = (size_t)atol(e);
   // the boundary's bulk copies (r04): page-locked trace in / FRI proof out on SDMA engines through the HSA runtime by default (measured with 8 provers in flight,

@@ -85,6 +85,10 @@ class HostStark:
                                       k.ctypes.data_as(C.POINTER(C.c_int)), sc.ctypes.data_as(C.POINTER(C.c_uint64)), ix.ctypes.data_as(C.POINTER(C.c_int)),
                                       C.c_int({"async": 2, "into": 3}.get(read_fri_proof, 1 if read_fri_proof else 0)))
 
+    def next_trace(self, host_ptr, N, w):
+        """msh_stark_next_trace: the page-locked trace of the proof after the next prove_raw - that call prefetches it (ms_trace_upload_async)."""
+        self.H.msh_stark_next_trace(self.h, C.c_void_p(host_ptr), C.c_size_t(N), C.c_size_t(w))
+
     def blob_checksum(self, which=0):
         """FNV-1a over the FRI blob of the last (0) / previous (1) proof, read in place from its page-locked slot (msh_proof_blob_checksum)."""
         return int(self.H.msh_proof_blob_checksum(self.h, C.c_int(which)))

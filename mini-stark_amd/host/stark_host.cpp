@@ -158,6 +158,7 @@ struct Stark {
   // land in the slot's page-locked buffer while the caller goes on - e.g. into the next prove; wait_proof() / any accessor of the blob completes
   // it); 3 the query-phase kernels write the blob straight INTO the slot's page-locked buffer (ms_fri_query_into: no copy at all)
   int wait_proof() const { return cfg.ctx ? ms_fri_proof_wait(cfg.ctx) : 0; }
+  const u64* next_host = nullptr; size_t next_N = 0, next_w = 0;
   int prove(const TraceTable& trace, int read_fri_proof) {
     const StarkConfig& c = cfg; ms_ctx* ctx = c.ctx; const int e = c.e; const u64 p = c.p;
     std::swap(proof, prev);   // (PinnedBuf moves by pointer swap below: the buffers stay where the device writes them)
@@ -169,6 +170,8 @@ struct Stark {
     if (trace.device) rc = ms_trace_commit_device(ctx, trace.device, trace.length, trace.width, c.trace_columns, pr.trace_commit);
     else rc = ms_trace_commit(ctx, trace.host, trace.length, trace.width, c.trace_columns, pr.trace_commit);
     if (rc) return rc;
+    // the NEXT proof's trace (msh_stark_next_trace), if the caller named one: its upload travels on an SDMA engine while this proof computes (ms_trace_upload_async)
+    if (next_host) { const u64* nh = next_host; next_host = nullptr; if ((rc = ms_trace_upload_async(ctx, nh, next_N, next_w))) return rc; }
     t.add_bytes(pr.trace_commit, 32);
     // 1.2 coset LDE of the constraint polynomials + commit (starks.rs:80-95)
     u64 shift; t.challenge_scalars(&shift, 1, p); if (!shift) shift = 1;
@@ -409,6 +412,8 @@ int msh_stark_prove(msh_stark* h, const u64* trace_host, const void* trace_dev, 
   }
   return h->s.prove(t, read_fri_proof);
 }
+// names the page-locked host trace of the proof AFTER the next msh_stark_prove: that call prefetches it right behind its own trace commitment
+void msh_stark_next_trace(msh_stark* h, const u64* trace_host, size_t N, size_t w) { h->s.next_host = trace_host; h->s.next_N = N; h->s.next_w = w; }
 size_t msh_proof_arthur(const msh_stark* h, u8* out, size_t cap) { return copy_out(h->s.proof.arthur.data(), h->s.proof.arthur.size(), out, cap); }
 int msh_proof_commits(const msh_stark* h, u8* trace_commit, u8* lde_commit) { memcpy(trace_commit, h->s.proof.trace_commit, 32); memcpy(lde_commit, h->s.proof.constrain_trace_commit, 32); return 0; }
 size_t msh_proof_evals(const msh_stark* h, u64* out, size_t cap_elems) { return copy_out(h->s.proof.evals.data(), h->s.proof.evals.size() * 8, out, cap_elems * 8) / 8; }

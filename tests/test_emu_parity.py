@@ -552,3 +552,15 @@ def test_copy_engine_failures_fail_closed(monkeypatch, field):
     assert ctx.trace_upload_async(pa, N, 3) == 0
     assert ctx.trace_commit_ptr(pa, N, 3, 6)[0] == ms.ERR_HIP and ctx.interpolate() == ms.ERR_STATE
     ctx.close()
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("log_n,blowup,tail_max,fused", [(8, 8, "0", False), (8, 8, "8192", True), (10, 8, "1048576", True), (9, 2, "1048576", True), (6, 16, "64", True), (11, 1, "4096", True)])
+def test_fri_tail_rounds_fused_and_launch_per_step(monkeypatch, field, log_n, blowup, tail_max, fused):
+    """r05: a tail round of the FRI commit phase as ONE launch - fold, DEEP quotient, trimmed length, pointwise codeword, leaf digests with their
+    pad-only blocks in place, every tree level, root and length to the host - against the oracle, forced off, at the default threshold and forced far up (several
+    evaluation-side workgroups and a tree top for the last one to finish; blowup 1 / 2: scans of more than one block fall back)."""
+    def set_env(k, v):
+        monkeypatch.delenv(k, raising=False) if v is None else monkeypatch.setenv(k, v)
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+    pc.case_fri_tail(lambda f: ms.Context(f, lib_path=EMU), field, log_n, blowup, tail_max, set_env, fused)

@@ -693,3 +693,45 @@ def test_sharded_2p22_rows_on_4_gloo_ranks_matches_unsharded():
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     calls = {int(k): v for k, v in res["calls"].items()}
     assert res["world"] == 4 and calls[0] >= 10 and calls[2] == 1 and calls[3] == 1 and res["dist_rounds"] >= 9, res
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("log_n,blowup,tail_max,fused", [(13, 8, "0", False), (13, 8, "8192", True), (16, 8, "1048576", True), (12, 2, "1048576", True), (10, 16, "64", True)])
+def test_fri_tail_rounds_fused_and_launch_per_step(monkeypatch, field, log_n, blowup, tail_max, fused):
+    """r05: a tail round of the FRI commit phase as ONE launch (csrc/fri_tail.hpp) on the real kernels - the completion counter, the device-scope
+    fences and the last workgroup's tree top included - against the oracle: off, at the default threshold, and forced up to 2^20-point domains (512 evaluation-side
+    workgroups, nine top levels)."""
+    if log_n >= 16:
+        orc.set_threads(8)
+    try:
+        pc.case_fri_tail(lambda f: ms.Context(f), field, log_n, blowup, tail_max, _env_setter(monkeypatch), fused)
+    finally:
+        orc.set_threads(1)
+
+
+@pytest.mark.parametrize("field,log_n", [(0, 13), (1, 12), (0, 16)])
+def test_latency_flag_side_stream_same_proof(field, log_n):
+    """r05: MS_FLAG_LATENCY - a FRI round's coefficient side (fold, DEEP-quotient scan, trimmed length) on a side stream beside its evaluation side, joined by an event in
+    front of the launch that forwards root and length word: the oracle's proof, twice on the same context (the second proof reuses streams, events and the length word)."""
+    if log_n >= 16:
+        orc.set_threads(8)
+    try:
+        ctx = ms.Context(field, flags=ms.FLAG_ZERO_DISPLAY_EMPTY | ms.FLAG_LATENCY)
+        for _ in range(2):
+            pc.case_prove(lambda f, fresh=False: ctx, field, log_n, 8, read_big=False)
+        ctx.close()
+    finally:
+        orc.set_threads(1)
+
+
+@pytest.mark.parametrize("latency", [False, True])
+def test_many_contexts_in_flight_prove_the_same(latency):
+    """r05: twelve proving threads, one context each, from their FIRST proof on (lazy buffers, plans, streams), every stage output against a single-lane proof
+    (tools/multi_lane_check.py).  The parity suite proves on one context at a time; the race this found - the length word zeroed lazily on one stream while the other
+    stream's scan already wrote it, visible only from eight lanes up - is the kind it cannot see."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "multi_lane_check.py"), "--lanes", "12", "--log-rows", "17", "--proofs", "4"] + (["--latency"] if latency else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
