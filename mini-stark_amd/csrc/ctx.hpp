@@ -152,6 +152,7 @@ template <class F> struct Ctx : CtxBase {
   // sh_on: the sharded code paths are active.  Normally that is world > 1; with MS_SHARD_WORLD1=1 (tests) a ONE-rank "world" runs them too - every exchange degenerates to a
   // transfer to itself, but every kernel, buffer offset, stream ordering and RCCL call of the sharded prover executes, through whole proofs, on one GPU
   bool sh_on = false; int allow_w1 = 0;
+  int shard_stub = 0;   // MS_SHARD_STUB=1 (the rank probe): ms_set_shard without a callback = a world without peers, every exchange a device copy of the rank's own payload
   u8* xs = nullptr; u8* xr = nullptr; size_t xcap = 0;   // caller-owned exchange buffers (device)
   ms_exchange_fn xfn = nullptr; void* xuser = nullptr;
   size_t shard_min_leaves = 32768;                        // MS_SHARD_MIN_LEAVES: smaller commitments stay replicated
@@ -299,7 +300,7 @@ template <class F> struct Ctx : CtxBase {
   u32* host_root() const { return reinterpret_cast<u32*>(reinterpret_cast<u8*>(pinned) + 256); }
   bool root_on_host = false;
   unsigned long long* pending_aux = nullptr; bool aux_on_host = false;   // a device word the tree's final launch forwards to pinned[0] (the degree result)
-  int inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_levels = true);
+  int inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_levels = true, u8* rec_out = nullptr);
   // Sharded MerkleTree::new over a binary tree of M = leaf_num/lpn leaf groups, of which this rank hashes the groups
   // j = rank + W*i found at local group index i of the view (base, strides): digest all-to-all, subtree, root all-gather, top.
   template <int EL>
@@ -525,7 +526,7 @@ template <class F> struct Ctx : CtxBase {
   // fri.rs:96-109
   int fri_fold_commit(const u64* alpha, u8* root) override;
   // MS_FRI_TAIL_MAX: rounds folding a domain of at most this many points run as ONE launch (fri_tail.hpp; 0: never).  Same-box A/B: DESIGN.md
-  size_t fri_tail_max = (size_t)1 << 13;
+  size_t fri_tail_max = (size_t)1 << 15;   // (8192 / 32768 / 131072: within noise of each other alone and with eight in flight, profiles/r05_fri_tail_ab.log; 2^15 = every replicated round of a sharded proof at the default MS_SHARD_MIN_LEAVES)
   // MS_FLAG_LATENCY (r05): the coefficient side of a round's ms_fri_fold_commit (fold, DEEP quotient scan, trimmed length: ~55 us of small launches) on a SIDE stream
   // while the evaluation side (pointwise codeword, leaf hashing, tree) runs on the context's stream - the two are independent (the codeword never reads the
   // quotient); the launch that forwards root and length word to the host waits for the side stream's event.  The fused tail rounds do the same inside one kernel.

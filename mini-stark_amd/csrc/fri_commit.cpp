@@ -267,14 +267,10 @@ int Ctx<F>::fold_dist(Round* pr, Round* nr, const XE& a, size_t* nq_coef_out) {
   size_t nq_coef = 0;
   PartScope part(this);
   if (m >= 2) {
-    typename mspoly::FoldKernel<F, E>::Params fp{lpoly(pr), lstride(pr), cntp, d_folded.as<T>(), Sn, a};  // fri.rs:361-372
-    CK(run<mspoly::FoldKernel<F, E>>(K_FOLD, grid1(cnt, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
-    T* pay = reinterpret_cast<T*>(xs);        // [first folded element (E limbs) | aggregate of the job (E limbs)]
-    CK(msrt::memset_dev(xs, 0, 2 * E * sizeof(T), stream));
-    if (cnt) {
-      typename mspoly::CopyLimbsKernel<F>::Params cl{d_folded.as<T>(), Sn, pay, 1, (u32)E};
-      CK(run<mspoly::CopyLimbsKernel<F>>(K_IO, 1, 1, mspoly::CopyLimbsKernel<F>::THREADS, 0, cl));
-    }
+    T* pay = reinterpret_cast<T*>(xs);        // [first folded element (E limbs) | aggregate of the job (E limbs)]: the fold's first thread writes [f_0 | 0], the aggregate launch the rest
+    typename mspoly::FoldKernel<F, E>::Params fp{lpoly(pr), lstride(pr), cntp, d_folded.as<T>(), Sn, a, pay};  // fri.rs:361-372
+    if (cnt) CK(run<mspoly::FoldKernel<F, E>>(K_FOLD, grid1(cnt, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
+    else CK(msrt::memset_dev(xs, 0, 2 * E * sizeof(T), stream));   // (a rank with no coefficient of this round: an all-zero payload)
     const size_t mj = cnt ? cnt - 1 : 0;
     SHPlan pl; pl.nl = 0;
     if (mj) {
@@ -333,7 +329,7 @@ int Ctx<F>::fri_tail_round(Round* pr, Round* nr, const XE& a, bool* done) {
   memset(&tp, 0, sizeof tp);
   // ---- coefficient side
   tp.do_coef = m >= 2 ? 1 : 0;
-  tp.fold = typename TK::FoldK::Params{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a};
+  tp.fold = typename TK::FoldK::Params{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a, nullptr};
   if (tp.do_coef) {
     SHPlan sp = sh_plan(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), false, nr->cap, 0, 1, nullptr, d_sh.as<T>());
     if (sp.nl != 1) return fail(MS_ERR_STATE, "fused FRI round: scan of more than one block");
@@ -396,7 +392,7 @@ int Ctx<F>::fri_fold_commit(const u64* alpha, u8* root) {
     side = fri_overlap && !prof_on;   // (the per-kernel profile times launches one behind the other on ONE stream)
     if (side && !side_stream) { CK(msrt::stream_create(&side_stream)); CK(msrt::event_create(&ev_side)); }
     StreamScope on_side(this, side ? side_stream : stream);
-    typename mspoly::FoldKernel<F, E>::Params fp{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a};  // fri.rs:361-372
+    typename mspoly::FoldKernel<F, E>::Params fp{pr->poly.template as<T>(), pr->cap, n, d_folded.as<T>(), m, a, nullptr};  // fri.rs:361-372
     CK(run<mspoly::FoldKernel<F, E>>(K_FOLD, grid1(m, mspoly::THREADS), 1, mspoly::THREADS, 0, fp));
     // (folded - B(alpha)) / (x - z): quotient coefficients are H_1.. of the suffix Horner in z (fri.rs:99-101)
     RQ(suffix_horner(d_folded.as<T>(), m, 0, 1, m, cur_z, nr->poly.template as<T>(), nr->cap, 0, 1, nullptr));

@@ -690,20 +690,27 @@ struct CopyRangesKernel {
     for (size_t i = w0 + (size_t)tid; i < w0 + WORDS && i < nw; i += (size_t)nthreads) dst[i] = src[i];
   }
 };
-// top of a sharded tree: the W all-gathered (root | aux) records -> W contiguous roots, and the maximum of the ranks' aux words (the trimmed length of a
-// distributed round polynomial rides on the root all-gather: no collective of its own)
-struct ShardTopKernel {
-  static constexpr int THREADS = 64;
+// Top of a sharded tree: the W all-gathered (root | aux) records -> W contiguous roots, the maximum of the ranks' aux words (the trimmed length of a distributed round
+// polynomial rides on the root all-gather: no collective of its own), and the levels above the W roots in the SAME launch (r05: two launches until then; every launch
+// of this chain is latency on every rank): one workgroup unpacks the records, then walks the log2(W) levels with the children in LDS (InnerSubtreeKernel's device code),
+// the root and the (maximum) aux word forwarded as `tree` says.  W <= 2^MAX_LEVELS.
+struct ShardTopTreeKernel {
+  static constexpr int THREADS = InnerSubtreeKernel::THREADS;
   static constexpr int REC = 64;   // bytes per rank: 32-byte root, 8-byte aux, padding
-  struct Params { const unsigned char* recs; u32 W; u32* top; unsigned long long* aux_max; };
-  static MS_HD int nphases(const Params&) { return 1; }
-  static MS_DEV void phase(int, const Params& p, int, int, int tid, int nthreads, unsigned char*) {
-    for (u32 i = (u32)tid; i < p.W * 8; i += (u32)nthreads) p.top[i] = reinterpret_cast<const u32*>(p.recs + (size_t)(i / 8) * REC)[i % 8];
+  struct Params { const unsigned char* recs; u32 W; unsigned long long* aux_max; InnerHashParams tree; /* nodes = the top's node array, child_off 0, nchildren W, nlevels log2 W */ };
+  static MS_HD size_t lds_bytes() { return InnerSubtreeKernel::lds_bytes(); }
+  static MS_DEV void run(const Params& p, int, int, int, int tid, unsigned char* lds) {
+    for (u32 i = (u32)tid; i < p.W * 8; i += (u32)THREADS) p.tree.nodes[i] = reinterpret_cast<const u32*>(p.recs + (size_t)(i / 8) * REC)[i % 8];
     if (tid == 0 && p.aux_max) {
       unsigned long long m = 0;
       for (u32 r = 0; r < p.W; r++) { const unsigned long long v = *reinterpret_cast<const unsigned long long*>(p.recs + (size_t)r * REC + 32); if (v > m) m = v; }
       *p.aux_max = m;
     }
+    msrt::wg_barrier_global();   // level 0 reads the roots other threads just stored
+    if (p.tree.nlevels) { InnerSubtreeKernel::run(p.tree, 0, 0, 1, tid, lds); return; }
+    // a one-rank world: the lone subtree root is the root
+    if (p.tree.host_root && tid < 8) p.tree.host_root[tid] = p.tree.nodes[tid];
+    if (p.tree.host_root && tid == 8 && p.tree.aux_src) { *p.tree.aux_dst = *p.tree.aux_src; *p.tree.aux_src = 0; }
   }
 };
 // MerklePath of a sharded binary tree, same layout as PathKernel; every byte is written by exactly ONE rank

@@ -62,9 +62,17 @@ int Ctx<F>::tree_build(const T* base, size_t col_stride, size_t row_stride, size
 }
 
 template <class F>
-int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_levels) {
+int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_levels, u8* rec_out) {
   size_t child_off = 0;
   if (final_levels) root_on_host = false;
+  // rec_out (a subtree of a sharded tree, final_levels false): the launch that produces the subtree's root also stores the rank's record of the root all-gather -
+  // root at rec_out, the aux word (shard_aux, if any) 32 bytes behind it - instead of a fill and two copy launches behind the subtree (r05)
+  bool rec_done = false;
+  auto to_rec = [&](msmerkle::InnerHashKernel::Params& ip) {
+    ip.host_root = reinterpret_cast<u32*>(rec_out);
+    if (shard_aux) { ip.aux_src = shard_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(rec_out + 32); }
+    rec_done = true;
+  };
   while (nchildren > 1) {
     msmerkle::InnerHashKernel::Params ip;
     ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic; ip.host_root = nullptr; ip.aux_src = nullptr; ip.aux_dst = nullptr;
@@ -77,7 +85,7 @@ int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_lev
         RQ(join_side());   // this launch forwards the length word the side stream's scan produces
         ip.host_root = host_root(); root_on_host = true;
         if (pending_aux) { ip.aux_src = pending_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
-      }
+      } else if (rec_out && left == 1) to_rec(ip);
       ip.nlevels = nl;
       next_bytes = (double)nchildren * 32 * 2;
       CK(run_coop<SK>(K_INNER_HASH, (unsigned)left, SK::THREADS, SK::lds_bytes(), ip));
@@ -88,7 +96,7 @@ int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_lev
       RQ(join_side());
       ip.host_root = host_root(); root_on_host = true;
       if (pending_aux) { ip.aux_src = pending_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
-    }
+    } else if (rec_out && (nparents == 1 || nparents <= (size_t)tree_top_parents)) to_rec(ip);
     if (nparents <= (size_t)tree_top_parents) {  // fused tree top: one workgroup walks the remaining levels
       u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ic) nl++;
       ip.nlevels = nl;
@@ -102,6 +110,10 @@ int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_lev
     if (ic == 2) CK(run<msmerkle::InnerHashKernel2>(K_INNER_HASH, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
     else CK(run<msmerkle::InnerHashKernel>(K_INNER_HASH, (unsigned)((nparents + msmerkle::THREADS - 1) / msmerkle::THREADS), 1, msmerkle::THREADS, 0, ip));
     child_off += nchildren; nchildren = nparents;
+  }
+  if (rec_out && !rec_done) {   // no launch took the record along (a one-digest "subtree"): by copies
+    CK(msrt::d2d(rec_out, reinterpret_cast<u8*>(nodes) + (child_off + nchildren - 1) * 32, 32, stream));
+    if (shard_aux) CK(msrt::d2d(rec_out + 32, shard_aux, 8, stream)); else CK(msrt::memset_dev(rec_out + 32, 0, 8, stream));
   }
   return 0;
 }
@@ -139,18 +151,26 @@ int Ctx<F>::tree_build_sharded(const T* base, size_t col_stride, size_t row_stri
 template <class F>
 int Ctx<F>::finish_sharded_tree(TreeShape& ts, DevBuf& nodes, size_t Mloc) {
   const size_t W = (size_t)sh_world, sub_nodes = 2 * Mloc - 1, top_nodes = 2 * W - 1;
-  constexpr size_t REC = msmerkle::ShardTopKernel::REC;
+  constexpr size_t REC = msmerkle::ShardTopTreeKernel::REC;
   if (W * REC > xcap) return fail(MS_ERR_NOMEM, "exchange buffers too small for the subtree roots");
-  { PartScope part(this); RQ(inner_levels(nodes.as<u32>(), Mloc, 2, false)); }
-  CK(msrt::memset_dev(xs, 0, REC, stream));
-  CK(msrt::d2d(xs, nodes.as<u8>() + (sub_nodes - 1) * 32, 32, stream));
-  if (shard_aux) CK(msrt::d2d(xs + 32, shard_aux, 8, stream));
+  // the subtree; its last launch leaves this rank's record (root | aux word) in the send buffer.  (Bytes 40 .. 64 of a record are never read.)
+  { PartScope part(this); RQ(inner_levels(nodes.as<u32>(), Mloc, 2, false, xs)); }
   RQ(exchange(MS_XCHG_ALL_GATHER, REC));
+  // the W records -> the top's leaves, the maximum aux word, and the levels above them, in one launch; root (and the length word riding on the commitment) to the host
   u8* top = nodes.as<u8>() + sub_nodes * 32;
-  msmerkle::ShardTopKernel::Params tk{xr, (u32)W, reinterpret_cast<u32*>(top), shard_aux};
-  CK(run<msmerkle::ShardTopKernel>(K_IO, 1, 1, msmerkle::ShardTopKernel::THREADS, 0, tk));
+  typedef msmerkle::ShardTopTreeKernel TT;
+  if (W > ((size_t)1 << msmerkle::InnerSubtreeKernel::MAX_LEVELS)) return fail(MS_ERR_STATE, "sharded tree: more ranks than the top kernel's levels");
+  typename TT::Params tk;
+  memset(&tk, 0, sizeof tk);
+  tk.recs = xr; tk.W = (u32)W; tk.aux_max = shard_aux;
+  tk.tree.nodes = reinterpret_cast<u32*>(top); tk.tree.child_off = 0; tk.tree.nchildren = W; tk.tree.ic = 2;
+  u32 tl = 0; while (((size_t)1 << tl) < W) tl++;
+  tk.tree.nlevels = tl;
+  RQ(join_side());
+  tk.tree.host_root = host_root(); root_on_host = true;
+  if (pending_aux) { tk.tree.aux_src = pending_aux; tk.tree.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
   shard_aux = nullptr;
-  RQ(inner_levels(reinterpret_cast<u32*>(top), W, 2));
+  CK(run_coop<TT>(K_INNER_HASH, 1, TT::THREADS, TT::lds_bytes(), tk));
   ts.sharded = true; ts.Mloc = Mloc; ts.local_nodes = sub_nodes + top_nodes;
   return 0;
 }
@@ -205,7 +225,7 @@ int Ctx<F>::merkle_commit(const u64* leafs, size_t leaf_num, int ext, size_t lpn
 // the members this unit defines, for both fields (the other units see declarations only)
 #define MS_INSTANTIATE(FF) \
   template int Ctx<FF>::tree_shape(size_t leaf_num, size_t lpn, size_t ic, Ctx<FF>::TreeShape* ts); \
-  template int Ctx<FF>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_levels); \
+  template int Ctx<FF>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_levels, u8* rec_out); \
   template int Ctx<FF>::finish_sharded_tree(Ctx<FF>::TreeShape& ts, DevBuf& nodes, size_t Mloc); \
   template int Ctx<FF>::read_root(const DevBuf& nodes, const Ctx<FF>::TreeShape& ts, u8* root); \
   template int Ctx<FF>::merkle_commit(const u64* leafs, size_t leaf_num, int ext, size_t lpn, size_t ic, u8* nodes_out, size_t cap, size_t* nn, u8* root);

@@ -328,7 +328,9 @@ template <class F, int E> struct ReducePartialsKernel {
 template <class F, int E> struct FoldKernel {
   typedef typename F::T T;
   static constexpr int THREADS = mspoly::THREADS;
-  struct Params { const T* src; size_t src_limb_stride, n; T* dst; size_t dst_limb_stride; Ext<F, E> alpha; };
+  // first_out (optional; a rank of a sharded proof): the first folded element also goes to first_out[0 .. E) and E zero limbs behind it - the payload of the scan's carry
+  // exchange ([first element | aggregate]; the aggregate launch overwrites the zeros), which took a fill and a copy launch of its own until r05
+  struct Params { const T* src; size_t src_limb_stride, n; T* dst; size_t dst_limb_stride; Ext<F, E> alpha; T* first_out; };
   static MS_HD int nphases(const Params&) { return 1; }
   static MS_DEV void phase(int, const Params& p, int bx, int, int tid, int nthreads, unsigned char*) {
     const size_t j = (size_t)bx * nthreads + tid;
@@ -339,6 +341,7 @@ template <class F, int E> struct FoldKernel {
     if (2 * j + 1 < p.n) for (int l = 0; l < E; l++) od.c[l] = p.src[(size_t)l * p.src_limb_stride + 2 * j + 1];
     Ext<F, E> r = e_add<F, E>(ev, e_mul<F>(p.alpha, od));
     for (int l = 0; l < E; l++) p.dst[(size_t)l * p.dst_limb_stride + j] = r.c[l];
+    if (j == 0 && p.first_out) for (int l = 0; l < E; l++) { p.first_out[l] = r.c[l]; p.first_out[E + l] = 0; }
   }
 };
 

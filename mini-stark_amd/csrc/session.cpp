@@ -119,6 +119,7 @@ int Ctx<F>::init(int dev, u32 flags) {
   if (const char* e = getenv("MS_SHARD_MIN_LEAVES")) { long v = atol(e); if (v >= 1) shard_min_leaves = (size_t)v; }
   if (const char* e = getenv("MS_SHARD_DIST")) shard_dist = atoi(e);
   if (const char* e = getenv("MS_SHARD_WORLD1")) allow_w1 = atoi(e);
+  if (const char* e = getenv("MS_SHARD_STUB")) shard_stub = atoi(e);
   if (const char* e = getenv("MS_SHARD_GATHER_CHUNK")) { long v = atol(e); if (v >= 64) shard_gather_chunk = (size_t)v & ~(size_t)63; }
   if (const char* e = getenv("MS_SHARD_SLICES")) { int v = atoi(e); if (v >= 1 && v <= 64) { shard_slices = v; shard_slices_set = true; } }
   if (const char* e = getenv("MS_SHARD_SLICE_MIN")) { long v = atol(e); if (v >= 1) shard_slice_min = (size_t)v; }

@@ -50,6 +50,14 @@ int Ctx<F>::exchange(int op, size_t bytes) {
     if (e) { err = std::string("RCCL error ") + std::to_string(e) + (R.err_string ? std::string(": ") + R.err_string(e) : std::string()); return MS_ERR_HIP; }
     return 0;
   }
+  if (!xfn) {
+    // MS_SHARD_STUB (tools/shard_rank_probe.py: what ONE rank of W computes, measured on one GPU): no peers exist - every collective returns this rank's own payload in
+    // every peer's place, as stream-ordered device copies, no host synchronisation (like the RCCL path).  Right sizes, wrong values: the proof is garbage by construction.
+    const size_t W = (size_t)sh_world;
+    if (op == MS_XCHG_ALL_TO_ALL) CK(msrt::d2d(xr, xs, bytes * W, stream));
+    else if (op == MS_XCHG_ALL_GATHER || op == MS_XCHG_GATHER) { for (size_t r = 0; r < W; r++) CK(msrt::d2d(xr + r * bytes, xs, bytes, stream)); }
+    return 0;   // (the all-reduces leave the buffer as it is)
+  }
   CK(msrt::sync(stream));
   if (xfn(xuser, op, bytes)) return fail(MS_ERR_HIP, "exchange callback failed");
   return 0;
@@ -79,6 +87,7 @@ int Ctx<F>::exchange_slice(size_t off, size_t stride, size_t bytes, int sl, int 
     if (sl == S - 1) CK(msrt::stream_wait_event(stream, ev_xchg[sl]));   // the communication stream runs in order: the last slice's event covers all of them
     return 0;
   }
+  if (!xfn) { for (int r = 0; r < sh_world; r++) CK(msrt::d2d(xr + off + (size_t)r * stride, xs + off + (size_t)r * stride, bytes, stream)); return 0; }   // (stub world: see exchange)
   CK(msrt::sync(stream));
   xl_off = off; xl_stride = stride;
   if (xfn(xuser, MS_XCHG_ALL_TO_ALL_SLICE, bytes)) return fail(MS_ERR_HIP, "exchange callback failed");
@@ -179,7 +188,7 @@ int Ctx<F>::rccl_selftest() {
 template <class F>
 int Ctx<F>::set_shard(int rank, int world, void* d_send, void* d_recv, size_t cap, ms_exchange_fn fn, void* user) {
   if (world < 1 || !is_pow2((u64)world) || rank < 0 || rank >= world) return fail(MS_ERR_ARG, "set_shard: world must be a power of two and 0 <= rank < world");
-  if (world > 1 && (!d_send || !d_recv || !fn || cap < 4096)) return fail(MS_ERR_ARG, "set_shard: exchange buffers / callback missing");
+  if (world > 1 && (!d_send || !d_recv || (!fn && !shard_stub) || cap < 4096)) return fail(MS_ERR_ARG, "set_shard: exchange buffers / callback missing");
   drop_rccl();
   sh_rank = rank; sh_world = world; xs = reinterpret_cast<u8*>(d_send); xr = reinterpret_cast<u8*>(d_recv); xcap = cap; xfn = fn; xuser = user;
   sh_on = world > 1 || (allow_w1 && d_send && d_recv && fn && cap >= 4096);

@@ -17,19 +17,24 @@ ap.add_argument("--log-rows", type=int, default=20)
 ap.add_argument("--worlds", type=int, nargs="+", default=[2, 4, 8])
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--dist", type=int, nargs="+", default=[1, 0], help="MS_SHARD_DIST values to compare (1: coefficient-domain work partitioned, 0: replicated as in r03)")
+ap.add_argument("--python-stub", action="store_true")
 args = ap.parse_args()
+if not args.python_stub:
+    os.environ["MS_SHARD_STUB"] = "1"
 dev = torch.device("cuda", 0)
 N = 1 << args.log_rows
 blowup = 8
 
 
 class Stub:
+    """A world without peers.  Default (r05): the library's own stub (MS_SHARD_STUB=1: stream-ordered device copies, no host synchronisation - what the in-library RCCL
+    path costs a rank on the host side); --python-stub: the r04 form, a Python callback with torch copies and a device synchronisation per exchange."""
     def __init__(self, ctx, rank, world, cap):
         self.ctx, self.W = ctx, world
         self.send = torch.zeros(cap, dtype=torch.uint8, device=dev)
         self.recv = torch.zeros(cap, dtype=torch.uint8, device=dev)
         self.calls = {}
-        ctx.set_shard(rank, world, self.send.data_ptr(), self.recv.data_ptr(), cap, self.cb)
+        ctx.set_shard(rank, world, self.send.data_ptr(), self.recv.data_ptr(), cap, self.cb if args.python_stub else None)
 
     def cb(self, op, n):
         self.calls[op] = self.calls.get(op, 0) + 1
@@ -88,7 +93,7 @@ def one(world, dist):
     res = {"world": world, "shard_dist": dist, "log_rows": args.log_rows, "ms_wall_min": round(min(ts), 3), "ms_wall_all": [round(t, 3) for t in ts],
            "kernel_ms_total": round(sum(v["ms"] for v in prof.values()), 3), "partitioned_ms": sh.get("partitioned_ms"), "replicated_ms": sh.get("replicated_ms"),
            "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}, "replicated_by_kernel": sh.get("replicated_by_kernel"),
-           "launches": sum(v["launches"] for v in prof.values()), "collective_calls": stub.calls if stub else {}}
+           "launches": sum(v["launches"] for v in prof.values()), "collective_calls": (stub.calls if args.python_stub else {i: c for i, c in enumerate(ctx.shard_stats()[:4])}) if stub else {}}
     if stub:
         ctx.set_shard(0, 1, 0, 0, 0, None)
     ctx.close()
