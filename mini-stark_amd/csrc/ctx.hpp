@@ -547,6 +547,23 @@ template <class F> struct Ctx : CtxBase {
   // no read-back copy afterwards (r02: the runtime executed most of the 64 MiB read-back as shader copies, -15 % on the I/O-inclusive rate)
   bool blob_external = false;
   int fri_query(const u64* betas, int nq, u8* ext_out, size_t ext_cap, size_t* ext_len) override;
+  // what the steps of one query phase share (fri_query.cpp): blob layout, host-side job tables, their offsets in the one uploaded table area
+  struct QueryPlan {
+    typedef mspoly::CarryJob<F, E> CJ; typedef mspoly::FindJob<F, E> FJ; typedef msmerkle::PathJob<F, E> PJ; typedef msmerkle::ShardPathJob<F, E> SPJ;
+    size_t W = 0; int nq = 0; size_t pos = 0; u8* blob = nullptr;
+    T* d_h0 = nullptr; T* d_tg = nullptr; unsigned long long* d_ix = nullptr;          // H_0 outputs of the scans | find-first targets | found leaf indices
+    std::vector<size_t> rec_off, path_off; std::vector<u64> qlen; std::vector<T> x1h;
+    std::vector<std::vector<SHJ>> tables; std::vector<int> table_mode, table_part; size_t n_agg_tables = 0;   // launch order: every aggregate launch, then - behind the carry exchange - every final launch
+    std::vector<CJ> carry_jobs; bool any_dist = false;                                 // sharded proofs: carry-ins of the ranks' scan jobs
+    std::vector<msmerkle::CopyJob> unp; std::vector<size_t> unp_first, unp_cnt, chunk_c0, chunk_len;   // ... and the slices' way into the blob, chunk by chunk
+    std::vector<FJ> fjobs; std::vector<PJ> pjobs; std::vector<SPJ> sjobs; std::vector<msmerkle::CopyJob> cjobs; size_t stage_bytes = 0;
+    std::vector<size_t> toff; size_t off_f = 0, off_p = 0, off_sp = 0, off_cj = 0, off_rec = 0, off_ql = 0, off_x1 = 0, off_cr = 0, off_un = 0; const u8* dt = nullptr;
+  };
+  int query_layout(QueryPlan& q, int nq);
+  int query_build(QueryPlan& q, const u64* betas);
+  int query_scans(QueryPlan& q);
+  int query_shard_assembly(QueryPlan& q);
+  int query_openings(QueryPlan& q);
   size_t fri_proof_size() const override { return blob_size; }
   int fri_proof_read(u8* out) override;
   // The same copy on the context's COPY stream, ordered behind the query phase by an event: the call returns at once and the next proof's

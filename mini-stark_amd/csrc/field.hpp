@@ -261,8 +261,12 @@ struct BB {
   static constexpr u32 R2 = 1172168163u;  // 2^64 mod p
   static MS_HD T redc(u64 x) {
     const u32 m = (u32)x * MU;
-    const u32 t = (u32)((x + (u64)m * (u64)P) >> 32);  // x + m*p < 2^63 + 2^63
-    return t >= (u32)P ? t - (u32)P : t;
+    const u32 t = (u32)((x + (u64)m * (u64)P) >> 32);  // x + m*p < 2^63 + 2^63; t < 2p
+    // r05: the final correction as in add / sub - the smaller of t and t - p as unsigned numbers (t < p: t - p wraps above t) = v_sub + v_min_u32.  The
+    // `t >= p ? t - p : t` it replaces compiled to v_cmp_lt_u64 + v_add + v_cndmask, ~12 issue cycles against ~6 (tools/isa_census.py on the NTT pass kernels:
+    // one in twelve VALU instructions of a BabyBear pass was that compare; tools/valu_rate.hip: compares and v_cndmask issue at half the rate of adds)
+    const u32 r = t - (u32)P;
+    return r < t ? r : t;
   }
   // canonical in, canonical out: (a*b/R) * R^2 / R  — two 32x32 products + two reductions instead of a 64-bit modulo
   static MS_HD T mul(T a, T b) { return redc((u64)redc((u64)a * (u64)b) * (u64)R2); }

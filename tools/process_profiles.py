@@ -148,8 +148,8 @@ shutil.copy(O + "/bench_default.json", f"profiles/{R}_bench_default.json")
 # which kernel source these counters belong to: bench.py compares it with the source it runs (a kernel change without re-profiling shows as stale)
 import hashlib
 hsh = hashlib.sha256()
-for fn in ("ntt.hpp", "field.hpp", "merkle.hpp", "poly.hpp"):
+for fn in ("ntt.hpp", "field.hpp", "merkle.hpp", "poly.hpp", "fri_tail.hpp"):
     hsh.update(open(os.path.join("mini-stark_amd", "csrc", fn), "rb").read())
-json.dump({"round": R, "kernel_source_sha256": hsh.hexdigest(), "files": ["ntt.hpp", "field.hpp", "merkle.hpp", "poly.hpp"], "profile_run_started_at": T0, "profile_run_rc": done["rc"],
+json.dump({"round": R, "kernel_source_sha256": hsh.hexdigest(), "files": ["ntt.hpp", "field.hpp", "merkle.hpp", "poly.hpp", "fri_tail.hpp"], "profile_run_started_at": T0, "profile_run_rc": done["rc"],
            "every_pass_succeeded": True}, open(f"profiles/{R}_profile_meta.json", "w"))
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step")}), bench["roofline"])

@@ -29,5 +29,5 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/bb_write -- 
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/bb_sq -- python3 tools/ntt_bench.py --field 1 --log-rows 20 --reps 3 > $O/bb_sq.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/gl_sq -- python3 tools/ntt_bench.py --field 0 --log-rows 20 --reps 3 > $O/gl_sq.log 2>&1
 python3 tools/pmc_summary.py $O/gl_sq $O/bb_sq > $O/sq_counters_ntt_passes.txt 2>&1 || true
-rocprofv3 --kernel-trace --output-format csv -d $O/trace1 -- python3 bench.py --inflight 1 --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/trace1.log 2>&1 && python3 tools/trace_gaps.py $O/trace1 > $O/single_proof_timeline.txt 2>&1 || true
+rocprofv3 --kernel-trace --output-format csv -d $O/trace1 -- python3 bench.py --inflight 1 --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/trace1.log 2>&1 && python3 tools/trace_gaps.py $O/trace1 --dump > $O/single_proof_timeline.txt 2>&1 || true
 ls $O
