@@ -43,6 +43,13 @@ impl Gpu {
         self.check(unsafe { ms_trace_commit(self.ctx, trace.as_ptr(), n, w, lpn, root.as_mut_ptr()) })?;
         Ok(root)
     }
+    /// Optional, for a pipelined prover: queues the upload of the NEXT proof's trace (page-locked memory from `ms_pinned_alloc`) on a copy engine while the
+    /// current proof computes; the `trace_commit` that later passes the same slice finds it on the device.  A hint: `Ok(())` also when nothing was queued.
+    /// SAFETY of the contract: `trace` must stay alive and unchanged until that `trace_commit` has returned.
+    pub fn trace_upload_async(&mut self, trace: &[u64], n: usize, w: usize) -> Result<(), GpuError> {
+        assert_eq!(trace.len(), n * w);
+        self.check(unsafe { ms_trace_upload_async(self.ctx, trace.as_ptr(), n, w) })
+    }
     /// air.rs:147-160: TraceTable::get_trace_polys (per-column INTT)
     pub fn interpolate(&mut self) -> Result<(), GpuError> { self.check(unsafe { ms_interpolate(self.ctx) }) }
     /// air.rs:127-144: a transition closure that is a linear combination of earlier polynomials (tests/e2e_goldilocks.rs:48-59)

@@ -574,7 +574,7 @@ template <class F> struct Ctx : CtxBase {
   // hipMemcpyAsync on the copy stream (A/B); io_engine() reports which path the last read-back took.
   int readback_sdma = 2, sdma_gpu = -1, sdma_state = 0 /* 0 untried, 1 bound, 2 unavailable */, last_io_engine = 0;
   msrt::Sdma::Signal sdma_sig{0}, sdma_up_sig{0}; bool sdma_pending = false; int upload_sdma = 1;
-  u8* readback_dst = nullptr;          // destination of the read-back in flight (a FAILED engine copy is redone through the HIP runtime)
+  u8* readback_dst = nullptr; size_t readback_bytes = 0;   // destination and size of the read-back in flight (a FAILED engine copy is redone through the HIP runtime)
   double sdma_timeout_s = 20.0;        // MS_SDMA_TIMEOUT_S: how long a stage waits for a copy engine before it poisons the context
   bool sdma_ready();
   int poison(const char* what);        // -> MS_ERR_HIP now, MS_ERR_STATE from every later entry point

@@ -118,7 +118,7 @@ int Ctx<F>::fri_proof_read_async(u8* out) {
     CK(msrt::sync(stream));
     msrt::Sdma& S = msrt::Sdma::get();
     const int e = S.copy_d2h(sdma_gpu, out, d_blob.p, blob_size, sdma_sig, S.d2h_engine(sdma_gpu));
-    if (!e) { sdma_pending = true; copy_pending = true; readback_dst = out; last_io_engine = 1; return MS_OK; }
+    if (!e) { sdma_pending = true; copy_pending = true; readback_dst = out; readback_bytes = blob_size; last_io_engine = 1; return MS_OK; }
     sdma_state = 2;       // refused (engine id / access / a runtime that does not know the buffers): this context stays on the runtime's copy from here on
   }
   last_io_engine = 0;
@@ -139,7 +139,7 @@ int Ctx<F>::fri_proof_wait() {
     sdma_pending = false; copy_pending = false;
     if (wv < 0) {   // the engine reported a FAILED copy (negative completion signal): `out` holds garbage or nothing - once more through the HIP runtime
       sdma_state = 2; last_io_engine = 0;
-      CK(msrt::d2h(readback_dst, d_blob.p, blob_size, stream));
+      CK(msrt::d2h(readback_dst, d_blob.p, readback_bytes, stream));   // (readback_bytes, not blob_size: the next ms_fri_query has reset that by the time it waits for this copy)
       CK(msrt::sync(stream));
     }
     return MS_OK;

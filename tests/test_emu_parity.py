@@ -412,7 +412,7 @@ def test_sharded_code_paths_on_one_rank(monkeypatch, field, log_n, blowup, env, 
     assert st[0] >= 3 and st[1] > st[0] and st[2] == 1 and st[3] == 1 and dist_rounds >= 2
 
 
-def _prove_raw(ctx, field, trace, seed=9, upload=None, read="blocking", prefetch_next=None):
+def _prove_raw(ctx, field, trace, seed=9, upload=None, read="blocking", prefetch_next=None, wait=True):
     """One proof through the raw ABI on `ctx`; returns (rc of the first failing stage or 0, outputs).  upload = host pointer of a copy of the trace in "page-locked"
     memory (ms_pinned_alloc), read = "blocking" | "async" (ms_fri_proof_read_async + wait into a pinned buffer); prefetch_next = (ptr, N, w) handed to
     ms_trace_upload_async right behind the trace commitment."""
@@ -462,11 +462,11 @@ def _prove_raw(ctx, field, trace, seed=9, upload=None, read="blocking", prefetch
     n = ctx.fri_proof_size()
     buf = ctx.pinned_alloc(n)          # (not freed here: a copy that never completes may still "own" it - the test's context frees nothing under it either)
     rc = ctx.L.ms_fri_proof_read_async(ctx.h, C.c_void_p(buf))
-    if rc == 0:
+    if rc == 0 and wait:
         rc = ctx.L.ms_fri_proof_wait(ctx.h)
-    if rc == 0:
+    if rc == 0 and wait:
         outs.append(C.string_at(buf, n))
-    return rc, outs, buf
+    return rc, outs, buf, n
 
 
 @pytest.mark.parametrize("field", [0, 1])
@@ -521,6 +521,11 @@ def test_copy_engine_failures_fail_closed(monkeypatch, field):
     assert r[0] == 0 and r[1] == want and ctx.L.ms_io_engine(ctx.h) == 0
     r = _prove_raw(ctx, field, trace, upload=pa, read="async")                                 # (the failed prefetch is redone by the commit)
     assert r[0] == 0 and r[1] == want
+    # a failed read-back nobody waited for: the NEXT proof's query phase waits for it (before it rewrites the blob) and redoes it through the runtime's copy - whole proof, right size
+    r1 = _prove_raw(ctx, field, trace, upload=pa, read="async", wait=False)
+    assert r1[0] == 0
+    r2 = _prove_raw(ctx, field, other, read="async")
+    assert r2[0] == 0 and r2[1] == want_other and C.string_at(r1[2], r1[3]) == want[-1]
     ctx.close()
 
     # ---- hang (read-back): poisoned context

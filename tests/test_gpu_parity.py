@@ -427,6 +427,12 @@ def test_async_proof_readback_on_gpu(mk):
     assert hs.last_proof().fri_proof.blob == want[-1]
     # r04: the asynchronous read-back travels on an SDMA engine through the HSA runtime (never a blit kernel) unless MS_READBACK=hip
     assert ctx.L.ms_io_engine(ctx.h) == (0 if os.environ.get("MS_READBACK") == "hip" else 1), "the SDMA read-back did not bind: " + ctx.last_error()
+    # r05: the copy engines go through the HSA runtime ALREADY mapped into the process (never one the library loads itself), and the library says which
+    if os.environ.get("MS_READBACK") != "hip":
+        path = ctx.io_runtime_path()
+        assert "libhsa-runtime64" in path and os.path.exists(path), path
+        mapped = [l.split()[-1] for l in open("/proc/self/maps") if "libhsa-runtime64" in l]
+        assert os.path.realpath(path) in {os.path.realpath(m) for m in mapped}, (path, sorted(set(mapped)))   # (the loader's name of it may be a symlink)
 
 
 @pytest.mark.parametrize("mode", ["hip", "sdma-async", "sdma"])
