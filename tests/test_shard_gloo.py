@@ -89,3 +89,11 @@ def test_sharded_proof_with_half_empty_coefficient_ranges(world, field, log_n):
     empty and one rank holds the ragged top - empty scan jobs, zero aggregates in the carry chain, slices of length zero in the proof gather."""
     res = run_world(world, field, log_n, 8, 16, 29200 + world * 10 + field * 3 + log_n, mode="low-degree")
     assert res["world"] == world and res["dist_rounds"] >= 2
+
+
+@pytest.mark.parametrize("world,field,log_n", [(4, 0, 10), (2, 1, 9)])
+def test_sharded_proof_with_launch_per_step_tail_rounds(world, field, log_n):
+    """r05: the replicated rounds of a sharded proof run as fused rounds by default (csrc/fri_tail.hpp); MS_FRI_TAIL_MAX=0 keeps the launch-per-step path they replaced
+    covered in sharded mode (replicated fold / scan / degree / tree launches between distributed rounds and the query phase)."""
+    res = run_world(world, field, log_n, 8, 16, 29840 + world + field, env={"MS_FRI_TAIL_MAX": "0"})
+    assert res["world"] == world and res["dist_rounds"] >= 2
