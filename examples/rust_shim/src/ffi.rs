@@ -13,7 +13,7 @@ pub const MS_FIELD_GOLDILOCKS: ms_field = 0; // field.rs:36-56
 pub const MS_FIELD_BABYBEAR: ms_field = 1; // field.rs:66-109
 pub const MS_FLAG_ZERO_DISPLAY_EMPTY: u32 = 1; // ark-ff 0.5 prints Fp::ZERO as ""
 pub const MS_FLAG_TRACE_MONT64: u32 = 2; // ms_trace_commit* reads arkworks memory (Montgomery form, R = 2^64)
-pub const MS_FLAG_LATENCY: u32 = 4; // one proof alone on the GPU: independent chains of a stage on two streams
+pub const MS_FLAG_LATENCY: u32 = 4; // one proof alone on the GPU: independent chains of a stage on two streams, the calling thread spins for a stage's results
 pub const MS_FLAGS_DEFAULT: u32 = MS_FLAG_ZERO_DISPLAY_EMPTY;
 pub type ms_exchange_fn = Option<unsafe extern "C" fn(user: *mut c_void, op: c_int, bytes: usize) -> c_int>;
 

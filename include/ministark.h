@@ -54,8 +54,11 @@ typedef enum {
 #define MS_FLAG_TRACE_MONT64 0x2u       /* ms_trace_commit* input is arkworks memory: Montgomery form x*2^64 mod p, one u64 limb
                                           (`Fp<MontBackend<_,1>,1>`, src/field.rs:47,76); everything else stays canonical */
 #define MS_FLAG_LATENCY 0x4u            /* this context proves ALONE on its GPU and the caller wants the shortest proof, not the most proofs: independent chains of
-                                         * a stage (a FRI round's coefficient side and evaluation side) run on two streams.  With several contexts in flight it
-                                         * costs throughput (the side streams compete for HIP's few hardware queues: -15 % at 8 in flight): leave it off there. */
+                                         * a stage (a FRI round's coefficient side and evaluation side) run on two streams, and the calling thread SPINS on a
+                                         * page-locked word the stage's last kernel stores behind its results instead of blocking in the stream synchronisation
+                                         * (4-5 us less per transcript round trip, 44 of them per proof; a stage longer than 2 ms falls back to the blocking wait).
+                                         * With several contexts in flight it costs throughput (the side streams compete for HIP's few hardware queues: -15 % at
+                                         * 8 in flight; every proving thread burns a core while it waits): leave it off there. */
 #define MS_FLAGS_DEFAULT MS_FLAG_ZERO_DISPLAY_EMPTY
 
 /* ---- context ------------------------------------------------------------ */

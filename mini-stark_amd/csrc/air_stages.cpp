@@ -204,6 +204,16 @@ int Ctx<F>::mix(u64 r) {
   typename mspoly::MixKernel<F>::Params p{d_polys.as<T>(), N, N, npolys, F::from_u64(r), d_polys.as<T>() + (size_t)npolys * N};
   CK(run<mspoly::MixKernel<F>>(K_MIX, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, p));
   }
+  // the trimmed length ms_fri_begin needs (fri.rs:74), found HERE: the word travels to the host on DEEP-ALI's last evaluation launch (ms_eval_ext), which the caller
+  // waits for anyway - ms_fri_begin then starts its transform without a launch, a copy and a host round trip of its own (r05)
+  validity_len_host = false; validity_len_dev = nullptr;
+  if (!dist_eval()) {   // (a sharded proof's DEEP-ALI ends in a collective, not in an evaluation launch: ms_fri_begin keeps its own scan there)
+  RQ(ensure_evdone());
+  validity_len_dev = reinterpret_cast<unsigned long long*>(d_evdone.as<u8>() + 128);   // (a word of its own, not the zero pool: the pool may be wiped before ms_eval_ext comes)
+  CK(msrt::memset_dev(validity_len_dev, 0, 8, stream));
+  { typename mspoly::DegreeKernel<F, 1>::Params dp{d_polys.as<T>() + (size_t)npolys * N, 0, N, validity_len_dev, 0};
+    CK(run<mspoly::DegreeKernel<F, 1>>(K_DEGREE, grid1(N, mspoly::THREADS), 1, mspoly::THREADS, 0, dp)); }
+  }
   have_validity = true; validity_len = N; nrounds_done = 0;
   return MS_OK;
 }
@@ -251,6 +261,7 @@ int Ctx<F>::mix_cubic(u64 r, const int* spec, const u64* sc, int ncons) {
   CK(msrt::d2h(pinned, dres, 8, stream));
   CK(msrt::sync(stream));
   if (*reinterpret_cast<unsigned long long*>(pinned) > 2 * N) return fail(MS_ERR_SHAPE, "mix_cubic: the constraints do not vanish on the trace domain (the quotient by x^N - 1 is not a polynomial of 2N coefficients)");
+  validity_ncoef = (size_t)(*reinterpret_cast<unsigned long long*>(pinned)); validity_len_host = true; validity_len_dev = nullptr;   // (scaling by shift^-k keeps the trimmed length)
   const T shi = f_inv<F>(sh);
   RQ(scale_pow(coef, 0, d_polys.as<T>() + (size_t)npolys * N, 0, 2 * N, shi, 1));
   have_validity = true; validity_len = 2 * N; nrounds_done = 0;
@@ -295,10 +306,18 @@ int Ctx<F>::eval_views_i(const T* base, size_t poly_stride, size_t limb_stride, 
   XE sq = z;
   for (int i = 0; i < 9; i++) { p.zpow2[i] = sq; sq = e_mul<F>(sq, sq); }
   p.partials = nblocks > 1 ? d_partials.as<T>() : dst;  // single block: P_0 is the value
+  p.flag = msrt::HostFlag{nullptr, 0}; p.aux_src = nullptr; p.aux_dst = nullptr; p.single = nblocks == 1;
+  const bool arm = arm_next_eval; arm_next_eval = false;   // the caller's LAST evaluation: its results end the stage (sync_results)
+  const unsigned long long* fwd = fwd_next_eval; fwd_next_eval = nullptr;   // ... and a device word it takes along to host_aux2()
+  if (nblocks == 1) {
+    if (fwd) { p.aux_src = fwd; p.aux_dst = host_aux2(); }
+    if (arm) p.flag = arm_flag();
+  }
   CK(run_coop<EK>(K_EVAL, (unsigned)nblocks, EK::THREADS, EK::lds_bytes(), p));
   if (nblocks > 1) {
     typedef mspoly::ReducePartialsKernel<F, E> RK;
     typename RK::Params rp;
+    memset(&rp, 0, sizeof rp);
     rp.partials = d_partials.as<T>(); rp.nblocks = nblocks; rp.per_thread = (nblocks + RK::THREADS - 1) / RK::THREADS; rp.npoly = npoly; rp.out = dst;
     XE zc = p.zpow2[8];  // z^256
     for (int i = 256; i < (int)chunk; i *= 2) zc = e_mul<F>(zc, zc);  // z^CH
@@ -306,6 +325,8 @@ int Ctx<F>::eval_views_i(const T* base, size_t poly_stride, size_t limb_stride, 
     for (int i = 0; i < 8; i++) { rp.zs2[i] = zs; zs = e_mul<F>(zs, zs); }   // zc^(2^i)
     rp.zc_step = zs;                                                          // zc^256 = zc^THREADS
     static_assert(RK::THREADS == 256, "zc_step = zc^THREADS");
+    if (fwd) { rp.aux_src = fwd; rp.aux_dst = host_aux2(); }
+    if (arm) rp.flag = arm_flag();
     CK(run_coop<RK>(K_EVAL_REDUCE, 1, RK::THREADS, RK::lds_bytes(), rp));
   }
   return 0;
@@ -387,11 +408,14 @@ int Ctx<F>::eval_ext(const u64* z, int q, u64* out) {
       const int nb = (nev - i0 < mspoly::MAX_POLYS) ? nev - i0 : mspoly::MAX_POLYS;
       size_t off[mspoly::MAX_POLYS], cnt[mspoly::MAX_POLYS];
       for (int i = 0; i < nb; i++) { const int pi = ev[i0 + i]; off[i] = (size_t)pi * N; cnt[i] = (pi == npolys) ? validity_len : N; }   // the validity polynomial has 2N coefficients after ms_mix_cubic
+      arm_next_eval = t == q - 1 && i0 + mspoly::MAX_POLYS >= nev;
+      if (arm_next_eval && validity_len_dev && !validity_len_host) fwd_next_eval = validity_len_dev;
       RQ((eval_views<1>(d_polys.as<T>(), 0, 0, 1, off, cnt, nb, zz, reinterpret_cast<T*>(pinned) + ((size_t)t * nev + i0) * E)));   // results land in page-locked host memory
     }
   }
   if (tot) {
-    CK(msrt::sync(stream));
+    CK(sync_results());
+    if (validity_len_dev && !validity_len_host) { validity_ncoef = (size_t)*host_aux2(); validity_len_host = true; }
     RQ(eval_finish(q, ev, out));
   }
   return MS_OK;

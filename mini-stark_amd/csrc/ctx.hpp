@@ -205,7 +205,25 @@ template <class F> struct Ctx : CtxBase {
   }
   static const char* fname() { return F::ID == 0 ? "GL" : "BB"; }
   template <class A> static const char* aname() { return std::is_same<A, GLM>::value ? "GLM" : (std::is_same<A, GLT>::value ? "GLT" : (std::is_same<A, GL>::value ? "GL" : "BB")); }
+  // MS_FLAG_LATENCY: the launch that ends a stage raises a sequence number in page-locked memory behind its results (msrt::HostFlag, rt.hpp) and the host polls that
+  // word instead of synchronising with the stream (sync_results): 4-5 us less per host round trip, 44 of them per proof.  arm_flag() is for the Params of the NEXT
+  // launch only: run / run_coop move the number from "pending" to "armed" and every other launch disarms, so a stale number never stands for work enqueued behind it;
+  // stages that enqueue copies behind their last launch keep the stream synchronisation.
+  int poll_sync = 0;   // MS_FLAG_LATENCY at ms_create (MS_SYNC_POLL=0/1 overrides: A/B)
+  unsigned long long seq_no = 0, seq_pending = 0, seq_armed = 0;
+  unsigned long long* host_seq() const { return reinterpret_cast<unsigned long long*>(reinterpret_cast<u8*>(pinned) + pinned_cap); }   // (64 bytes behind the staging area)
+  msrt::HostFlag arm_flag() { if (!poll_sync || prof_on) return msrt::HostFlag{nullptr, 0}; seq_pending = ++seq_no; return msrt::HostFlag{host_seq(), seq_pending}; }
+  void launched() { seq_armed = seq_pending; seq_pending = 0; }
+  bool arm_next_eval = false;   // eval_views: the next evaluation is its caller's last (its launch carries the flag)
+  const unsigned long long* fwd_next_eval = nullptr;   // ... and takes this device word along to host_aux2()
+  unsigned long long* host_aux2() const { return host_seq() + 1; }
+  // trimmed length of the validity polynomial: a device word since ms_mix (validity_len_dev), on the host once ms_eval_ext has brought it along (validity_len_host)
+  unsigned long long* validity_len_dev = nullptr; bool validity_len_host = false; size_t validity_ncoef = 0;
+  DevBuf d_evdone;              // + 128: the validity polynomial's length word (ms_mix)
+  int ensure_evdone() { if (!d_evdone.p) { if (d_evdone.ensure(256)) return fail(MS_ERR_NOMEM, "length word"); CK(msrt::memset_dev(d_evdone.p, 0, 256, stream)); } return 0; }
+  int sync_results() { const unsigned long long a = seq_armed; seq_armed = 0; return a ? msrt::sync_flag(stream, host_seq(), a) : msrt::sync(stream); }
   template <class K> int run_coop(int kid, unsigned gx, int threads, size_t lds, const typename K::Params& p, unsigned gy = 1) {
+    launched();
     if (gx == 0 || gy == 0) return 0;
     if (!prof_on) return msrt::launch_coop<K>(stream, gx, gy, threads, lds, p);
     ProfRec r; r.kid = kid; r.sub = next_sub; r.bytes = next_bytes; r.part = part_depth > 0; next_bytes = 0; next_sub = 0;
@@ -217,6 +235,7 @@ template <class F> struct Ctx : CtxBase {
     return e;
   }
   template <class K> int run(int kid, unsigned gx, unsigned gy, int threads, size_t lds, const typename K::Params& p) {
+    launched();
     if (gx == 0 || gy == 0) return 0;
     if (!prof_on) return msrt::launch<K>(stream, gx, gy, threads, lds, p);
     ProfRec r; r.kid = kid; r.sub = next_sub; r.bytes = next_bytes; r.part = part_depth > 0; next_bytes = 0; next_sub = 0;
@@ -382,7 +401,7 @@ template <class F> struct Ctx : CtxBase {
     if (ev_copy) msrt::event_destroy(ev_copy);
     if (copy_stream) msrt::stream_destroy(copy_stream);
     for (Round* r : rounds) { r->poly.release(); r->cw.release(); r->nodes.release(); delete r; }
-    DevBuf* bufs[] = {&ntt_scratch, &d_trace[0], &d_trace[1], &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero, &d_lin, &d_cubic, &d_carry, &d_lq, &d_pack, &d_fullpoly};
+    DevBuf* bufs[] = {&ntt_scratch, &d_trace[0], &d_trace[1], &d_polys, &d_coef, &d_lde, &d_trace_nodes, &d_lde_nodes, &d_io, &d_partials, &d_small, &d_folded, &d_sh, &d_blob, &d_tabs, &d_targets, &d_idx, &d_deg, &d_ovf, &d_zero, &d_lin, &d_cubic, &d_carry, &d_lq, &d_pack, &d_fullpoly, &d_evdone};
     for (DevBuf* b : bufs) b->release();
     if (pinned) msrt::free_host(pinned);
     if (h_tabs) msrt::free_host(h_tabs);

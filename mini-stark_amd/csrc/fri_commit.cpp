@@ -121,7 +121,8 @@ int Ctx<F>::fri_begin(size_t blowup_, size_t nrounds, u8* root0) {
   CK(msrt::memset_dev(r->poly.p, 0, VL * E * sizeof(T), stream));
   CK(msrt::d2d(r->poly.p, d_polys.as<T>() + (size_t)npolys * N, VL * sizeof(T), stream));
   size_t nc;
-  RQ(read_degree_and_root(r->poly.template as<T>(), r->cap, VL, nullptr, &nc, nullptr));
+  if (validity_len_host) nc = validity_ncoef;   // (came to the host with DEEP-ALI's values: ms_mix scans, ms_eval_ext forwards)
+  else RQ(read_degree_and_root(r->poly.template as<T>(), r->cap, VL, nullptr, &nc, nullptr));
   r->ncoef = nc;
   const size_t deg = nc ? nc - 1 : 0;
   size_t dsize = (deg + 1) * blowup_;  // fri.rs:74 (quirk Q11)
@@ -150,8 +151,8 @@ int Ctx<F>::fri_deep(const u64* z, u64* B) {
     RQ(exchange(MS_XCHG_ALL_GATHER, 2 * E * sizeof(T)));
     RQ(shard_combine_launch(0, 2 * E, 2, e_pow<F, E>(cur_z, (u64)(r->S / 2)), dst));
   } else
-  RQ((eval_views<E>(r->poly.template as<T>(), 0, r->cap, 2, off, cnt, 2, cur_z, dst)));  // fri.rs:354-359
-  CK(msrt::sync(stream));
+  { arm_next_eval = true; RQ((eval_views<E>(r->poly.template as<T>(), 0, r->cap, 2, off, cnt, 2, cur_z, dst))); }  // fri.rs:354-359
+  CK(sync_results());
   const T* h = reinterpret_cast<const T*>(pinned);
   for (int s = 0; s < 2; s++) for (int l = 0; l < E; l++) { cur_B[s].c[l] = h[s * E + l]; B[s * E + l] = F::to_u64(h[s * E + l]); }
   have_deep = true;
@@ -351,7 +352,7 @@ int Ctx<F>::fri_tail_round(Round* pr, Round* nr, const XE& a, bool* done) {
   tp.sub.nodes = nr->nodes.template as<u32>(); tp.sub.child_off = 0; tp.sub.nchildren = M; tp.sub.ic = 2; tp.sub.nlevels = nl;
   u32 tl = 0; while (((size_t)1 << tl) < G) tl++;
   tp.top.nodes = nr->nodes.template as<u32>(); tp.top.child_off = 2 * M - 2 * G; tp.top.nchildren = G; tp.top.ic = 2; tp.top.nlevels = tl;
-  tp.top.host_root = host_root(); tp.top.aux_src = dres; tp.top.aux_dst = reinterpret_cast<unsigned long long*>(pinned);
+  tp.top.host_root = host_root(); tp.top.aux_src = dres; tp.top.aux_dst = reinterpret_cast<unsigned long long*>(pinned); tp.top.flag = arm_flag();
   tp.root_index = nr->ts.nodes - 1;
   tp.done = reinterpret_cast<u32*>(d_deg.as<u8>() + 128);            // (same zeroed line as the length word; the last workgroup leaves it zero)
   next_bytes = (double)Dn * E * sizeof(T) * 3 + (double)M * 96;
@@ -377,8 +378,8 @@ int Ctx<F>::fri_fold_commit(const u64* alpha, u8* root) {
   size_t nq_coef = 0;
   bool fused = false, side = false;
   RQ(fri_tail_round(pr, nr, a, &fused));
-  if (fused) {   // one launch did the whole round; the length word and the root are in page-locked memory behind the stream synchronisation
-    CK(msrt::sync(stream));
+  if (fused) {   // one launch did the whole round; the length word and the root are in page-locked memory behind the stream synchronisation (or the polled flag)
+    CK(sync_results());
     nr->ncoef = (size_t)(*reinterpret_cast<unsigned long long*>(pinned));
     memcpy(root, reinterpret_cast<const u8*>(host_root()), 32);
     nrounds_done++; have_deep = false;
@@ -419,11 +420,11 @@ int Ctx<F>::fri_fold_commit(const u64* alpha, u8* root) {
   if (side) { CK(msrt::event_record(ev_side, side_stream)); side_pending = true; }
   pending_aux = dres; aux_on_host = false;
   { auto clear = scope_exit([this] { pending_aux = nullptr; shard_aux = nullptr; });   // (also on an error exit: neither word may ride on the NEXT commitment's launches - ADVICE r4)
-    auto join = scope_exit([this] { if (side_pending) { side_pending = false; msrt::stream_wait_event(stream, ev_side); } });   // whatever path the commitment took (or left on): the context's stream ends behind the side stream
+    auto join = scope_exit([this] { if (side_pending) { side_pending = false; seq_armed = 0; msrt::stream_wait_event(stream, ev_side); } });   // whatever path the commitment took (or left on): the context's stream ends behind the side stream
     RQ(round_commit(nr, nq_coef, E, pr, &a)); }
-  if (!aux_on_host) { CK(msrt::d2h(pinned, dres, 8, stream)); CK(msrt::memset_dev(dres, 0, 8, stream)); }
-  if (!root_on_host) CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, nr->nodes.template as<u8>() + (nr->ts.local_nodes - 1) * 32, 32, stream));
-  CK(msrt::sync(stream));
+  if (!aux_on_host) { seq_armed = 0; CK(msrt::d2h(pinned, dres, 8, stream)); CK(msrt::memset_dev(dres, 0, 8, stream)); }
+  if (!root_on_host) { seq_armed = 0; CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 64, nr->nodes.template as<u8>() + (nr->ts.local_nodes - 1) * 32, 32, stream)); }
+  CK(sync_results());   // (polls the flag of the tree's last launch if nothing was enqueued behind it)
   nr->ncoef = (size_t)(*reinterpret_cast<unsigned long long*>(pinned));
   memcpy(root, root_on_host ? reinterpret_cast<const u8*>(host_root()) : reinterpret_cast<const u8*>(pinned) + 64, 32);
   nrounds_done++; have_deep = false;

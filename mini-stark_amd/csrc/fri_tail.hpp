@@ -88,8 +88,11 @@ template <class F, int E> struct FriTailKernel {
     msrt::fence_device();
     if (p.G > 1) { TreeK::run(p.top, 0, 0, 1, tid, lds); return; }
     // G == 1: the subtree root (or the lone leaf digest) is the tree's root - forward it, and the length word, to the host
-    if (tid < 8) p.top.host_root[tid] = p.top.nodes[p.root_index * 8 + (size_t)tid];
-    if (tid == 8 && p.top.aux_src) { *p.top.aux_dst = *p.top.aux_src; *p.top.aux_src = 0; }
+    if (tid == 0) {
+      for (int k = 0; k < 8; k++) p.top.host_root[k] = p.top.nodes[p.root_index * 8 + (size_t)k];
+      if (p.top.aux_src) { *p.top.aux_dst = *p.top.aux_src; *p.top.aux_src = 0; }
+      msrt::raise_host_flag(p.top.flag);
+    }
   }
 };
 

@@ -488,7 +488,8 @@ struct PadOnlyBlockKernel {
 // IC > 0: inner_children fixed at compile time (IC = 2 is the prover's tree, starks.rs:290-301: the padding block's
 // message schedule then folds to literals); IC = 0: taken from Params.
 struct InnerHashParams { u32* nodes; size_t child_off, nchildren; u32 ic; u32 nlevels; u32* host_root; /* optional: page-locked host memory that also receives the root (nparents == 1) */
-                         unsigned long long* aux_src; unsigned long long* aux_dst; /* optional: one more 8-byte result (the round polynomial's trimmed length) forwarded to page-locked host memory by the same thread */ };
+                         unsigned long long* aux_src; unsigned long long* aux_dst; /* optional: one more 8-byte result (the round polynomial's trimmed length) forwarded to page-locked host memory by the same thread */
+                         msrt::HostFlag flag; /* optional: raised behind root and aux word, for a host that polls instead of synchronising (rt.hpp) */ };
 template <int IC> struct InnerHashKernelT {
   static constexpr int THREADS = msmerkle::THREADS;
   typedef InnerHashParams Params;
@@ -531,6 +532,7 @@ template <int IC> struct InnerHashKernelT {
       if (p.host_root && nparents == 1) {   // saves the caller the copy launches (32-byte root, 8-byte degree word) in front of its stream synchronisation
         uint4_t* hr = reinterpret_cast<uint4_t*>(p.host_root); hr[0] = o0; hr[1] = o1;
         if (p.aux_src) { *p.aux_dst = *p.aux_src; *p.aux_src = 0; }   // ... and the device word is zero again for the next round's scan
+        msrt::raise_host_flag(p.flag);
       }
       if (stride == 0) break;
     }
@@ -594,6 +596,7 @@ struct InnerSubtreeKernel {
         if (p.host_root && nparents == 1) {
           uint4_t* hr = reinterpret_cast<uint4_t*>(p.host_root); hr[0] = o0; hr[1] = o1;
           if (p.aux_src) { *p.aux_dst = *p.aux_src; *p.aux_src = 0; }
+          msrt::raise_host_flag(p.flag);
         }
       }
       if (l + 1 < nl) msrt::wg_barrier();
@@ -709,8 +712,11 @@ struct ShardTopTreeKernel {
     msrt::wg_barrier_global();   // level 0 reads the roots other threads just stored
     if (p.tree.nlevels) { InnerSubtreeKernel::run(p.tree, 0, 0, 1, tid, lds); return; }
     // a one-rank world: the lone subtree root is the root
-    if (p.tree.host_root && tid < 8) p.tree.host_root[tid] = p.tree.nodes[tid];
-    if (p.tree.host_root && tid == 8 && p.tree.aux_src) { *p.tree.aux_dst = *p.tree.aux_src; *p.tree.aux_src = 0; }
+    if (p.tree.host_root && tid == 0) {
+      for (int k = 0; k < 8; k++) p.tree.host_root[k] = p.tree.nodes[k];
+      if (p.tree.aux_src) { *p.tree.aux_dst = *p.tree.aux_src; *p.tree.aux_src = 0; }
+      msrt::raise_host_flag(p.tree.flag);
+    }
   }
 };
 // MerklePath of a sharded binary tree, same layout as PathKernel; every byte is written by exactly ONE rank

@@ -75,7 +75,7 @@ int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_lev
   };
   while (nchildren > 1) {
     msmerkle::InnerHashKernel::Params ip;
-    ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic; ip.host_root = nullptr; ip.aux_src = nullptr; ip.aux_dst = nullptr;
+    ip.nodes = nodes; ip.child_off = child_off; ip.nchildren = nchildren; ip.ic = (u32)ic; ip.host_root = nullptr; ip.aux_src = nullptr; ip.aux_dst = nullptr; ip.flag = msrt::HostFlag{nullptr, 0};
     const size_t nparents = nchildren / ic;
     if (ic == 2 && nparents <= subtree_parents && (nchildren & (nchildren - 1)) == 0) {   // latency-bound levels: up to 9 of them per launch, children in LDS
       typedef msmerkle::InnerSubtreeKernel SK;
@@ -85,6 +85,7 @@ int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_lev
         RQ(join_side());   // this launch forwards the length word the side stream's scan produces
         ip.host_root = host_root(); root_on_host = true;
         if (pending_aux) { ip.aux_src = pending_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
+        ip.flag = arm_flag();
       } else if (rec_out && left == 1) to_rec(ip);
       ip.nlevels = nl;
       next_bytes = (double)nchildren * 32 * 2;
@@ -96,6 +97,7 @@ int Ctx<F>::inner_levels(u32* nodes, size_t nchildren, size_t ic, bool final_lev
       RQ(join_side());
       ip.host_root = host_root(); root_on_host = true;
       if (pending_aux) { ip.aux_src = pending_aux; ip.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
+      ip.flag = arm_flag();   // (the launch below is the tree's last either way: the fused top, or the level whose one parent is the root)
     } else if (rec_out && (nparents == 1 || nparents <= (size_t)tree_top_parents)) to_rec(ip);
     if (nparents <= (size_t)tree_top_parents) {  // fused tree top: one workgroup walks the remaining levels
       u32 nl = 0; for (size_t m = nchildren; m > 1; m /= ic) nl++;
@@ -169,6 +171,7 @@ int Ctx<F>::finish_sharded_tree(TreeShape& ts, DevBuf& nodes, size_t Mloc) {
   RQ(join_side());
   tk.tree.host_root = host_root(); root_on_host = true;
   if (pending_aux) { tk.tree.aux_src = pending_aux; tk.tree.aux_dst = reinterpret_cast<unsigned long long*>(pinned); pending_aux = nullptr; aux_on_host = true; }
+  tk.tree.flag = arm_flag();
   shard_aux = nullptr;
   CK(run_coop<TT>(K_INNER_HASH, 1, TT::THREADS, TT::lds_bytes(), tk));
   ts.sharded = true; ts.Mloc = Mloc; ts.local_nodes = sub_nodes + top_nodes;
@@ -192,8 +195,8 @@ int Ctx<F>::tree_build_sharded_contiguous(const T* base, size_t col_stride, size
 template <class F>
 int Ctx<F>::read_root(const DevBuf& nodes, const TreeShape& ts, u8* root) {
   const bool on_host = root_on_host;
-  if (!on_host) CK(msrt::d2h(pinned, nodes.as<u8>() + (ts.local_nodes - 1) * 32, 32, stream));
-  CK(msrt::sync(stream));
+  if (!on_host) { CK(msrt::d2h(pinned, nodes.as<u8>() + (ts.local_nodes - 1) * 32, 32, stream)); CK(msrt::sync(stream)); }
+  else CK(sync_results());   // (polls the flag the tree's last launch raises, if it carried one)
   memcpy(root, on_host ? reinterpret_cast<const void*>(host_root()) : pinned, 32);
   return 0;
 }

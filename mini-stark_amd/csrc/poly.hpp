@@ -198,6 +198,12 @@ template <class F, int EC, int E, int ITEMS_ = 16> struct EvalKernel {
     size_t off[MAX_POLYS], count[MAX_POLYS]; int npoly;
     Ext<F, E> zpow2[9];   // z^(2^i), i <= 8  (zpow2[8] = z^THREADS)
     T* partials;          // [nblocks][npoly][E]
+    // a SINGLE workgroup whose partial sums are the values, stored to page-locked host memory: flag and aux word as ReducePartialsKernel's.  (More than one workgroup:
+    // ReducePartialsKernel follows as a launch of its own - letting the last workgroup to finish sum the partials, as the fused FRI round does, was tried in r05 and
+    // cost 8-9 us MORE per evaluation than the second launch: 512 workgroups each paying a device-scope release in front of the counter.)
+    msrt::HostFlag flag;
+    const unsigned long long* aux_src; unsigned long long* aux_dst;
+    unsigned single;      // 1: this launch is that single workgroup
   };
   static MS_HD size_t lds_bytes() { return ((size_t)MAX_POLYS * E * (THREADS / 64) + 32 * (size_t)E) * sizeof(T); }
   // coefficient * power, the power in table form (e_to_tw)
@@ -265,6 +271,10 @@ template <class F, int EC, int E, int ITEMS_ = 16> struct EvalKernel {
       for (int t = 0; t < WAVES; t++) s = F::add(s, red[(size_t)tid * WAVES + t]);
       p.partials[(size_t)bx * width + tid] = s;
     }
+    if (p.single) {
+      if (tid == 0 && p.aux_src) *p.aux_dst = *p.aux_src;
+      msrt::raise_host_flag_wg(p.flag, tid);
+    }
   }
 };
 // out[i] = sum_b partials[b][i] * zc^b,  i < npoly (E limbs each), zc = z^CH.
@@ -276,7 +286,8 @@ template <class F, int E> struct ReducePartialsKernel {
   // sum_b P_b zc^b with thread t taking the blocks b = t, t + THREADS, t + 2 THREADS, ...: neighbouring lanes read neighbouring partials and the loads of a
   // thread do not depend on each other (r03: with a contiguous run of blocks per thread every iteration waited for its own uncoalesced load - 6.4 ms of the
   // 66 ms of a 2^24-row proof sat in this one-workgroup kernel).  zc = z^CH; zs2[i] = zc^(2^i), i < 8; zc_step = zc^THREADS.
-  struct Params { const T* partials; size_t nblocks, per_thread /* ceil(nblocks / THREADS) */; int npoly; Ext<F, E> zc_step; Ext<F, E> zs2[8]; T* out; };
+  struct Params { const T* partials; size_t nblocks, per_thread /* ceil(nblocks / THREADS) */; int npoly; Ext<F, E> zc_step; Ext<F, E> zs2[8]; T* out; msrt::HostFlag flag; /* raised behind `out` (page-locked host memory then) */
+                  const unsigned long long* aux_src; unsigned long long* aux_dst; /* optional: a device word that travels to page-locked host memory with the values (the validity polynomial's trimmed length, found by ms_mix, on DEEP-ALI's last evaluation) */ };
   static MS_HD size_t lds_bytes() { return (size_t)MAX_POLYS * E * (THREADS / 64) * sizeof(T); }
   static MS_DEV void run(const Params& p, int, int, int, int tid, unsigned char* lds) {   // cooperative: wave-shuffle block sum, as EvalKernel
     T* red = reinterpret_cast<T*>(lds);
@@ -320,6 +331,8 @@ template <class F, int E> struct ReducePartialsKernel {
       for (int t = 0; t < WAVES; t++) s = F::add(s, red[(size_t)tid * WAVES + t]);
       p.out[tid] = s;
     }
+    if (tid == 0 && p.aux_src) *p.aux_dst = *p.aux_src;
+    msrt::raise_host_flag_wg(p.flag, tid);
   }
 };
 

@@ -35,6 +35,7 @@ inline int d2h(void* h, const void* d, size_t n, Stream*) { std::memcpy(h, d, n)
 inline int d2d(void* d, const void* s, size_t n, Stream*) { std::memmove(d, s, n); return 0; }
 inline int memset_dev(void* d, int v, size_t n, Stream*) { std::memset(d, v, n); return 0; }
 inline int sync(Stream*) { return 0; }
+inline int sync_flag(Stream*, const unsigned long long* f, unsigned long long v) { return *f == v ? 0 : 999; }   // emulated launches are synchronous: the flag is up or it never will be
 inline int stream_create(Stream** s) { *s = new Stream(); return 0; }
 inline int stream_destroy(Stream* s) { delete s; return 0; }
 inline int set_device(int) { return 0; }
@@ -167,11 +168,16 @@ MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { unsigned o = *a; *a = 
 MS_DEV unsigned wave_alloc_slot(unsigned* counter, bool want) { if (!want) return 0; unsigned o = *counter; *counter = o + 1; return o; }
 // true if the predicate holds on any live lane of the wave (emulation: a wave of one lane — results must not depend on it)
 MS_DEV bool wave_any(bool pred) { return pred; }
+struct HostFlag { unsigned long long* dst; unsigned long long val; };
+MS_DEV void raise_host_flag(const HostFlag& f) { if (f.dst) *f.dst = f.val; }   // (an emulated launch has run to its end before the host looks)
+inline void raise_host_flag_wg(const HostFlag& f, int tid) { if (f.dst && tid == 0) *f.dst = f.val; }
 }  // namespace msrt
 MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 
 #else  // ---------------------------------------------------------------- HIP (gfx950)
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <ctime>
 #include <vector>
@@ -189,6 +195,21 @@ inline int d2h(void* h, const void* d, size_t n, Stream* s) { return (int)hipMem
 inline int d2d(void* d, const void* s_, size_t n, Stream* s) { return (int)hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s); }
 inline int memset_dev(void* d, int v, size_t n, Stream* s) { return (int)hipMemsetAsync(d, v, n, s); }
 inline int sync(Stream* s) { return (int)hipStreamSynchronize(s); }
+// host side of HostFlag (below): spin on the page-locked word for up to 2 ms, then fall back to the stream synchronisation (a long stage gains nothing from polling; a
+// failed launch never raises the flag and reports through the stream)
+inline int sync_flag(Stream* s, const unsigned long long* f, unsigned long long v) {
+  const volatile unsigned long long* vf = f;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned i = 1;; i++) {
+    if (*vf == v) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+    __builtin_ia32_pause();
+    if (!(i & 1023u) && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+  }
+  const int e = (int)hipStreamSynchronize(s);
+  if (e) return e;
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return *vf == v ? 0 : (int)hipErrorUnknown;
+}
 inline int stream_create(Stream** s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 inline int stream_destroy(Stream* s) { return (int)hipStreamDestroy(s); }
 inline int set_device(int d) { return (int)hipSetDevice(d); }
@@ -494,6 +515,22 @@ MS_DEV unsigned wave_alloc_slot(unsigned* counter, bool want) {
   if ((int)lane == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
   base = (unsigned)__shfl((int)base, leader);
   return base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+}
+// "this stage's results are in page-locked host memory": a sequence number the kernel that ends a stage stores BEHIND its results, for a host that polls the word
+// instead of synchronising with the stream (MS_FLAG_LATENCY: 6.4 instead of 11.0 us from launch to host-visible result, profiles/r05_latency_probe.txt).  Called by
+// the ONE thread that stored the results itself: system-scope fence (its stores have left for the host), then a system-scope release store of the word.
+struct HostFlag { unsigned long long* dst; unsigned long long val; };
+MS_DEV void raise_host_flag(const HostFlag& f) {
+  if (!f.dst) return;
+  __threadfence_system();
+  __hip_atomic_store(f.dst, f.val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... and the form for results several threads of ONE workgroup stored: called by every thread of the workgroup (f is uniform)
+MS_DEV void raise_host_flag_wg(const HostFlag& f, int tid) {
+  if (!f.dst) return;
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(f.dst, f.val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace msrt
 MS_HD uint64_t ms_mulhi64(uint64_t a, uint64_t b) {

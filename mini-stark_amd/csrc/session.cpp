@@ -92,7 +92,7 @@ int Ctx<F>::ensure_polys(size_t count) {
 
 template <class F>
 int Ctx<F>::init(int dev, u32 flags) {
-  device = dev; zae = (flags & MS_FLAG_ZERO_DISPLAY_EMPTY) ? 1 : 0; trace_mont = (flags & MS_FLAG_TRACE_MONT64) ? 1 : 0; fri_overlap = (flags & MS_FLAG_LATENCY) ? 1 : 0;
+  device = dev; zae = (flags & MS_FLAG_ZERO_DISPLAY_EMPTY) ? 1 : 0; trace_mont = (flags & MS_FLAG_TRACE_MONT64) ? 1 : 0; fri_overlap = (flags & MS_FLAG_LATENCY) ? 1 : 0; poll_sync = fri_overlap;
   if (const char* e = getenv("MS_NTT_KMAX")) { int v = atoi(e); if (v >= 5 && v <= msntt::MAX_LOG_R) ntt_kmax = v; }
   if (const char* e = getenv("MS_NTT_FAST")) ntt_fast = atoi(e);
   if (const char* e = getenv("MS_NTT_V2")) ntt_v2 = atoi(e);
@@ -107,6 +107,7 @@ int Ctx<F>::init(int dev, u32 flags) {
   if (const char* e = getenv("MS_FOLD_SMALL_MAX")) fold_small_max = (size_t)atol(e);
   if (const char* e = getenv("MS_FRI_TAIL_MAX")) fri_tail_max = (size_t)atol(e);
   if (const char* e = getenv("MS_FRI_OVERLAP")) fri_overlap = atoi(e);
+  if (const char* e = getenv("MS_SYNC_POLL")) poll_sync = atoi(e);
   if (const char* e = getenv("MS_EVAL_SMALL_MAX")) eval_small_max = (size_t)atol(e);
   if (const char* e = getenv("MS_TREE_SUBTREE_PARENTS")) subtree_parents = (size_t)atol(e);
   // the boundary's bulk copies (r04): page-locked trace in / FRI proof out on SDMA engines through the HSA runtime by default (measured with 8 provers in flight,
@@ -128,7 +129,8 @@ int Ctx<F>::init(int dev, u32 flags) {
   CK(msrt::stream_create(&own_stream));
   stream = own_stream;
   pinned_cap = 1 << 16;
-  CK(msrt::malloc_host(&pinned, pinned_cap));
+  CK(msrt::malloc_host(&pinned, pinned_cap + 64));   // (+ the polled sequence word, host_seq())
+  *host_seq() = 0;
   if (d_small.ensure(4096)) return fail(MS_ERR_NOMEM, "small");
   return 0;
 }
@@ -189,17 +191,20 @@ int Ctx<F>::trace_commit(const u64* trace, bool on_device, size_t N_, size_t w_,
   // 2^-64 mod p: arkworks stores Montgomery representatives (R = 2^64 for the one-limb Fp of both fields)
   const T rinv = f_inv<F>(F::from_u64((u64)(((unsigned __int128)1 << 64) % F::P)));
   void* badw;
-  RQ(zero_alloc(4, &badw));  // device input cannot be range-checked on the host: the kernel flags elements >= p
+  RQ(zero_alloc(8, &badw));  // device input cannot be range-checked on the host: the kernel flags elements >= p
   RQ(transpose_in(dsrc, d_polys.as<T>(), N, w, rinv, trace_mont, reinterpret_cast<u32*>(badw)));
+  // the flag word rides to the host on the tree's last launch, like a round's length word (r05: the 4-byte copy behind the tree cost ~30 us of launch latency per proof)
+  pending_aux = reinterpret_cast<unsigned long long*>(badw); aux_on_host = false;
+  auto clear = scope_exit([this] { pending_aux = nullptr; });
   // element f of trace.get_data() = column f % w, row f / w of the column-major copy
   // one proof over several ranks: every rank holds the whole trace, so rank k hashes the contiguous leaf groups [k*M/W, (k+1)*M/W) and only the W subtree roots travel (r04)
   if (sh_on && shard_dist && shardable(ts.leaf_num / ts.lpn)) RQ((tree_build_sharded_contiguous<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
   else
   RQ((tree_build<1>(d_polys.as<T>(), N, 1, 0, (u32)w, ts, d_trace_nodes)));
   trace_ts = ts;
-  CK(msrt::d2h(reinterpret_cast<u8*>(pinned) + 128, badw, 4, stream));
+  if (!aux_on_host) { pending_aux = nullptr; seq_armed = 0; CK(msrt::d2h(pinned, badw, 8, stream)); if (root_on_host) CK(msrt::sync(stream)); }   // (a tree of one leaf group: no launch took it along)
   RQ(read_root(d_trace_nodes, ts, root));
-  if (*reinterpret_cast<const u32*>(reinterpret_cast<const u8*>(pinned) + 128)) return fail(MS_ERR_ARG, "trace element not canonical (>= p)");
+  if (*reinterpret_cast<const unsigned long long*>(pinned)) return fail(MS_ERR_ARG, "trace element not canonical (>= p)");
   have_trace = true;
   return MS_OK;
 }

@@ -569,3 +569,18 @@ def test_fri_tail_rounds_fused_and_launch_per_step(monkeypatch, field, log_n, bl
         monkeypatch.delenv(k, raising=False) if v is None else monkeypatch.setenv(k, v)
     subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
     pc.case_fri_tail(lambda f: ms.Context(f, lib_path=EMU), field, log_n, blowup, tail_max, set_env, fused)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("log_n,blowup", [(4, 8), (9, 8), (12, 4)])
+def test_latency_flag_polled_results(field, log_n, blowup):
+    """r05: MS_FLAG_LATENCY - the launch that ends a stage raises a sequence number behind its results and the host polls it instead of synchronising (ctx.hpp
+    arm_flag / sync_results; emulated launches are synchronous, so this covers the bookkeeping: every polled stage carried a flag, no stale number is ever waited for),
+    evaluation launches that sum their own partials, the trace's range flag riding on the tree's last launch.  The oracle's proof, twice on one context."""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+    ctx = ms.Context(field, lib_path=EMU, flags=ms.FLAG_ZERO_DISPLAY_EMPTY | ms.FLAG_LATENCY)
+    for _ in range(2):
+        pc.case_prove(lambda f, fresh=False: ctx, field, log_n, blowup, read_big=False)
+    pc.case_device_trace_range_check(lambda f, fresh=False: ctx, field, lambda a: (a.ctypes.data, a))
+    pc.case_prove(lambda f, fresh=False: ctx, field, 5, 8, read_big=False)   # ... and the context proves on behind the refused trace
+    ctx.close()

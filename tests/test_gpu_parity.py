@@ -717,10 +717,12 @@ def test_fri_tail_rounds_fused_and_launch_per_step(monkeypatch, field, log_n, bl
         orc.set_threads(1)
 
 
-@pytest.mark.parametrize("field,log_n", [(0, 13), (1, 12), (0, 16)])
+@pytest.mark.parametrize("field,log_n", [(0, 13), (1, 12), (0, 16), (0, 21)])
 def test_latency_flag_side_stream_same_proof(field, log_n):
     """r05: MS_FLAG_LATENCY - a FRI round's coefficient side (fold, DEEP-quotient scan, trimmed length) on a side stream beside its evaluation side, joined by an event in
-    front of the launch that forwards root and length word: the oracle's proof, twice on the same context (the second proof reuses streams, events and the length word)."""
+    front of the launch that forwards root and length word: the oracle's proof, twice on the same context (the second proof reuses streams, events and the length word).
+    The flag also makes the host POLL a sequence number the stage's last kernel stores behind its results instead of synchronising with the stream (ctx.hpp sync_results);
+    2^21 rows: stages longer than the 2 ms the host spins for, which fall back to the blocking wait."""
     if log_n >= 16:
         orc.set_threads(8)
     try:

@@ -12,7 +12,15 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def run_world(world, field, log_n, blowup, min_leaves, port, env=None, mode=""):
+    port = _free_port()   # (the callers' fixed numbers collided when xdist ran two parametrisations of one test side by side: a rendezvous failure once in a few runs)
     subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", os.path.join(HERE, "..", "oracle")], stdout=subprocess.DEVNULL)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",

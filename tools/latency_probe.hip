@@ -30,6 +30,13 @@ int main() {
     k_flag<<<1, 64, 0, s>>>(h, (uint32_t)i + 1);
     volatile uint32_t* f = h + 16; while (*f != (uint32_t)i + 1) {}
   });
+  run("1 kernel + spin on hipStreamQuery", [&](int) { k_empty<<<1, 64, 0, s>>>(d); while (hipStreamQuery(s) == hipErrorNotReady) {} });
+  run("5 dependent kernels, the last stores a flag the host polls (no sync)", [&](int i) {
+    for (int j = 0; j < 4; j++) k_empty<<<1, 64, 0, s>>>(d);
+    k_flag<<<1, 64, 0, s>>>(h, (uint32_t)i + 1);
+    volatile uint32_t* f = h + 16; while (*f != (uint32_t)i + 1) {}
+  });
+  run("5 dependent kernels + spin on hipStreamQuery", [&](int) { for (int j = 0; j < 5; j++) k_empty<<<1, 64, 0, s>>>(d); while (hipStreamQuery(s) == hipErrorNotReady) {} });
   hipEvent_t ev; CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   run("1 kernel + event record + hipEventSynchronize", [&](int) { k_empty<<<1, 64, 0, s>>>(d); (void)hipEventRecord(ev, s); (void)hipEventSynchronize(ev); });
   run("32-byte hipMemcpyAsync H2D (pinned) + 1 kernel + sync", [&](int) { (void)hipMemcpyAsync(d, h, 32, hipMemcpyHostToDevice, s); k_empty<<<1, 64, 0, s>>>(d); (void)hipStreamSynchronize(s); });

@@ -93,7 +93,7 @@ def one(world, dist):
     res = {"world": world, "shard_dist": dist, "log_rows": args.log_rows, "ms_wall_min": round(min(ts), 3), "ms_wall_all": [round(t, 3) for t in ts],
            "kernel_ms_total": round(sum(v["ms"] for v in prof.values()), 3), "partitioned_ms": sh.get("partitioned_ms"), "replicated_ms": sh.get("replicated_ms"),
            "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}, "replicated_by_kernel": sh.get("replicated_by_kernel"),
-           "launches": sum(v["launches"] for v in prof.values()), "collective_calls": (stub.calls if args.python_stub else {i: c for i, c in enumerate(ctx.shard_stats()[:4])}) if stub else {}}
+           "launches": sum(v["launches"] for v in prof.values()), "launches_by_kernel": {k: v["launches"] for k, v in prof.items() if v["launches"]}, "collective_calls": (stub.calls if args.python_stub else {i: c for i, c in enumerate(ctx.shard_stats()[:4])}) if stub else {}}
     if stub:
         ctx.set_shard(0, 1, 0, 0, 0, None)
     ctx.close()
