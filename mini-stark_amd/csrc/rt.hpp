@@ -29,6 +29,7 @@ struct Stream { int dummy; };
 inline int malloc_dev(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
 inline int free_dev(void* p) { std::free(p); return 0; }
 inline int malloc_host(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
+inline int malloc_host_coherent(void** p, size_t n) { return malloc_host(p, n); }
 inline int free_host(void* p) { std::free(p); return 0; }
 inline int h2d(void* d, const void* h, size_t n, Stream*) { std::memcpy(d, h, n); return 0; }
 inline int d2h(void* h, const void* d, size_t n, Stream*) { std::memcpy(h, d, n); return 0; }
@@ -189,6 +190,8 @@ typedef ihipStream_t Stream;
 inline int malloc_dev(void** p, size_t n) { return (int)hipMalloc(p, n ? n : 1); }
 inline int free_dev(void* p) { return (int)hipFree(p); }
 inline int malloc_host(void** p, size_t n) { return (int)hipHostMalloc(p, n ? n : 1, hipHostMallocDefault); }
+// ... fine-grained whatever HIP_HOST_COHERENT says: a kernel's stores are visible to the host while the kernel still runs (the context's staging area: polled results)
+inline int malloc_host_coherent(void** p, size_t n) { return (int)hipHostMalloc(p, n ? n : 1, hipHostMallocCoherent); }
 inline int free_host(void* p) { return (int)hipHostFree(p); }
 inline int h2d(void* d, const void* h, size_t n, Stream* s) { return (int)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); }
 inline int d2h(void* h, const void* d, size_t n, Stream* s) { return (int)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s); }

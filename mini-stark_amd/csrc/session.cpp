@@ -129,7 +129,7 @@ int Ctx<F>::init(int dev, u32 flags) {
   CK(msrt::stream_create(&own_stream));
   stream = own_stream;
   pinned_cap = 1 << 16;
-  CK(msrt::malloc_host(&pinned, pinned_cap + 64));   // (+ the polled sequence word, host_seq())
+  CK(msrt::malloc_host_coherent(&pinned, pinned_cap + 64));   // (+ the polled sequence word, host_seq())
   *host_seq() = 0;
   if (d_small.ensure(4096)) return fail(MS_ERR_NOMEM, "small");
   return 0;
