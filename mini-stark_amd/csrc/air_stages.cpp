@@ -297,6 +297,8 @@ int Ctx<F>::eval_views(const T* base, size_t poly_stride, size_t limb_stride, si
 template <class F> template <int EC, int ITEMS>
 int Ctx<F>::eval_views_i(const T* base, size_t poly_stride, size_t limb_stride, size_t kstride, const size_t* off, const size_t* count, int npoly, const XE& z, T* dst, size_t maxc) {
   typedef mspoly::EvalKernel<F, EC, E, ITEMS> EK;
+  const bool arm = arm_next_eval; arm_next_eval = false;   // the caller's LAST evaluation: its results end the stage (sync_results).  (Taken first: no exit below leaves it set)
+  const unsigned long long* fwd = fwd_next_eval; fwd_next_eval = nullptr;   // ... and a device word it takes along to host_aux2()
   const size_t chunk = (size_t)EK::THREADS * EK::ITEMS;
   const size_t nblocks = maxc ? (maxc + chunk - 1) / chunk : 1;
   if (nblocks > 1 && d_partials.ensure(nblocks * npoly * E * sizeof(T))) return fail(MS_ERR_NOMEM, "partials");
@@ -307,8 +309,6 @@ int Ctx<F>::eval_views_i(const T* base, size_t poly_stride, size_t limb_stride, 
   for (int i = 0; i < 9; i++) { p.zpow2[i] = sq; sq = e_mul<F>(sq, sq); }
   p.partials = nblocks > 1 ? d_partials.as<T>() : dst;  // single block: P_0 is the value
   p.flag = msrt::HostFlag{nullptr, 0}; p.aux_src = nullptr; p.aux_dst = nullptr; p.single = nblocks == 1;
-  const bool arm = arm_next_eval; arm_next_eval = false;   // the caller's LAST evaluation: its results end the stage (sync_results)
-  const unsigned long long* fwd = fwd_next_eval; fwd_next_eval = nullptr;   // ... and a device word it takes along to host_aux2()
   if (nblocks == 1) {
     if (fwd) { p.aux_src = fwd; p.aux_dst = host_aux2(); }
     if (arm) p.flag = arm_flag();

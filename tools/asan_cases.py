@@ -47,6 +47,17 @@ for field in (0, 1):
 del os.environ["MS_LDE_VIRTUAL"]
 for field in (0, 1):
     pc.case_arith_selftest(mk, field, nrand=256)
+# r05: MS_FLAG_LATENCY (polled results: flags raised by the trees' last launches, the fused rounds and the evaluations; range flag and length word riding along),
+# twice on one context, and the fused rounds with several evaluation-side workgroups
+for field in (0, 1):
+    lat = ms.Context(field, lib_path=EMU, flags=ms.FLAG_ZERO_DISPLAY_EMPTY | ms.FLAG_LATENCY)
+    for log_n, blowup in ((3, 8), (9, 8), (9, 8), (11, 2)):
+        pc.case_prove(lambda f, fresh=False: lat, field, log_n, blowup, read_big=False)
+    pc.case_device_trace_range_check(lambda f, fresh=False: lat, field, lambda a: (a.ctypes.data, a))
+    lat.close()
+os.environ["MS_FRI_TAIL_MAX"] = "1048576"
+pc.case_prove(lambda f, fresh=False: mk(f, fresh=True), 0, 10, 8)
+del os.environ["MS_FRI_TAIL_MAX"]
 from mini_stark_amd.host import build_host_library
 build_host_library()
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
