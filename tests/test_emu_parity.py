@@ -398,7 +398,8 @@ def test_c_abi_never_unwinds(field):
 
 
 @pytest.mark.parametrize("field,log_n,blowup,env,root_only,base_z", [(0, 10, 8, {}, False, ()), (1, 9, 8, {"MS_SHARD_SLICES": "4", "MS_SHARD_SLICE_MIN": "1"}, False, (1, 2)),
-                                                                    (0, 13, 8, {"MS_SHARD_GATHER_CHUNK": "4096"}, True, ()), (0, 8, 2, {}, False, ())])
+                                                                    (0, 13, 8, {"MS_SHARD_GATHER_CHUNK": "4096"}, True, ()), (0, 8, 2, {}, False, ()),
+                                                                    (0, 10, 8, {"MS_FRI_OVERLAP": "1", "MS_SYNC_POLL": "1"}, False, ()), (1, 9, 8, {"MS_SYNC_POLL": "1", "MS_FRI_TAIL_MAX": "0"}, True, (2,))])
 def test_sharded_code_paths_on_one_rank(monkeypatch, field, log_n, blowup, env, root_only, base_z):
     """r04: MS_SHARD_WORLD1=1 lets a one-rank world run the SHARDED prover (coset evaluation, digest exchange, subtree + top, distributed round polynomials with their carry
     chain, query slices, paths through the exchange buffer) inside one process, every exchange a copy to itself: same bytes as the oracle.  The GPU suite runs the same case on

@@ -633,13 +633,13 @@ def test_trace_upload_from_page_locked_memory(monkeypatch, upload):
 @pytest.mark.parametrize("field,log_n,rccl,env,root_only", [(0, 12, False, {}, False), (0, 16, True, {}, False), (1, 14, True, {"MS_SHARD_SLICES": "4", "MS_SHARD_SLICE_MIN": "64"}, True),
                                                            (0, 18, True, {"MS_SHARD_SLICES": "4", "MS_SHARD_MIN_LEAVES": "32768"}, False),
                                                            (0, 16, True, {"MS_RCCL_MAX_PIECE": "4096"}, True), (1, 14, True, {"MS_RCCL_MAX_PIECE": "1024", "MS_SHARD_SLICES": "2", "MS_SHARD_SLICE_MIN": "64"}, False),
-                                                           (0, 17, True, {"MS_FRI_OVERLAP": "1", "MS_SHARD_MIN_LEAVES": "4096", "MS_FRI_TAIL_MAX": "256"}, False), (1, 14, False, {"MS_FRI_TAIL_MAX": "0", "MS_FRI_OVERLAP": "1"}, True)])
+                                                           (0, 17, True, {"MS_FRI_OVERLAP": "1", "MS_SYNC_POLL": "1", "MS_SHARD_MIN_LEAVES": "4096", "MS_FRI_TAIL_MAX": "256"}, False), (1, 14, False, {"MS_FRI_TAIL_MAX": "0", "MS_FRI_OVERLAP": "1", "MS_SYNC_POLL": "1"}, True)])
 def test_sharded_code_paths_on_one_rank_on_gpu(monkeypatch, field, log_n, rccl, env, root_only):
     """The sharded prover on a one-rank world on the real kernels (MS_SHARD_WORLD1=1).  rccl=True: the exchanges are RCCL calls inside the library on a one-rank communicator -
     grouped ncclSend / ncclRecv (to itself), ncclAllGather, ncclAllReduce, the sliced digest exchange on its own stream behind events, the gather to rank 0 - so the RCCL branch,
     which no multi-GPU box has run yet, executes through whole proofs with real buffers and stream ordering, bit-exact against the oracle (2^18 rows with the default threshold).
     MS_RCCL_MAX_PIECE (r05): every transfer cut into pieces of that many bytes - the loop that keeps a single ncclSend / ncclRecv below 2 GiB (RCCL 2.26.6 delivers wrong bytes
-    beyond: test_config3_sharded_form_2p24_rows_matches_unsharded), forced at small sizes.  MS_FRI_OVERLAP=1 (r05): the latency mode's side stream in the replicated rounds of a
+    beyond: test_config3_sharded_form_2p24_rows_matches_unsharded), forced at small sizes.  MS_FRI_OVERLAP=1 MS_SYNC_POLL=1 (r05; what MS_FLAG_LATENCY sets): the latency mode's side stream and polled results (the sharded trees' top launch carries the flag; stages that end in a collective keep the stream synchronisation) in the replicated rounds of a
     sharded proof (distributed rounds keep one stream); MS_FRI_TAIL_MAX=0: those rounds launch per step instead of fused."""
     import torch
     monkeypatch.setenv("MS_SHARD_WORLD1", "1")

@@ -105,3 +105,11 @@ def test_sharded_proof_with_launch_per_step_tail_rounds(world, field, log_n):
     covered in sharded mode (replicated fold / scan / degree / tree launches between distributed rounds and the query phase)."""
     res = run_world(world, field, log_n, 8, 16, 29840 + world + field, env={"MS_FRI_TAIL_MAX": "0"})
     assert res["world"] == world and res["dist_rounds"] >= 2
+
+
+@pytest.mark.parametrize("world,field,log_n", [(4, 0, 10), (2, 1, 8)])
+def test_sharded_proof_with_latency_flag_settings(world, field, log_n):
+    """r05: what MS_FLAG_LATENCY sets (side stream for a replicated round's coefficient side, polled results) inside a sharded proof: the top launch of a sharded tree
+    carries the polled flag, stages that end in a collective keep the stream synchronisation - the oracle's bytes on every rank."""
+    res = run_world(world, field, log_n, 8, 16, 0, env={"MS_FRI_OVERLAP": "1", "MS_SYNC_POLL": "1"})
+    assert res["world"] == world and res["dist_rounds"] >= 2
