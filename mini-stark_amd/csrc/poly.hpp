@@ -762,16 +762,6 @@ template <class F, int E> struct GatherPolyKernel {
     p.dst[l * p.dst_limb_stride + g] = p.gathered[r * p.rank_stride + l * p.S + i];
   }
 };
-// n strided elements (the E limbs of one extension element out of an SoA vector into a packed payload, or back)
-template <class F> struct CopyLimbsKernel {
-  typedef typename F::T T;
-  static constexpr int THREADS = 64;
-  struct Params { const T* src; size_t src_stride; T* dst; size_t dst_stride; u32 n; };
-  static MS_HD int nphases(const Params&) { return 1; }
-  static MS_DEV void phase(int, const Params& p, int, int, int tid, int, unsigned char*) {
-    if ((u32)tid < p.n) p.dst[(size_t)tid * p.dst_stride] = p.src[(size_t)tid * p.src_stride];
-  }
-};
 
 // ---------------------------------------------------------------- build-defined degree-3 composition (ms_mix_cubic)
 // BASELINE configs[4] names "degree-3 constraints", which the reference cannot express (quirk Q1: its `validity` polynomial is the REMAINDER of the division by
