@@ -30,7 +30,8 @@ class MsError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libministark.so")
+    """The product library; MS_LIB_PATH names another build of it (same-box A/Bs of compile-time variants: tools/ab.sh)."""
+    return os.environ.get("MS_LIB_PATH") or os.path.join(_HERE, "libministark.so")
 
 
 def build_library(force=False):

@@ -136,6 +136,61 @@ struct Sha256 {
   }
 };
 
+// One inner node of the binary tree (64-byte message + its constant padding block) hashed by a PAIR of lanes (r05): the e-side (e, f, g, h) of a round in one lane,
+// the a-side (a, b, c, d) in its partner (msrt::pair_swap: lane ^ 7), as ONE instruction stream - per-lane rotation amounts, Maj(a, b, c) = Ch(a ^ c, b, c) so that one
+// bitop3 pair serves both, T1 and d exchanged by two bank-masked DPP adds, sigma0 / sigma1 of the message schedule split over the two lanes.  1800 VALU instructions per
+// node where Sha256 needs 2319: for the levels of a tree whose nodes are fewer than the lanes that could hash them a LEVEL is one node's dependent chain in a lone wave,
+// 3.39 instead of 4.09 us (tools/sha_pair_lab.hip, profiles/r05_sha_pair_lab.log).  Every lane of a pair calls every function below (the exchanges are wave operations).
+struct Sha256Pair {
+  u32 M, R1, R2, R3, Sa, Sb, Sc;   // a-lane mask; Sigma rotations (a-lane: Sigma0, e-lane: Sigma1); schedule rotations / shift (a-lane: sigma1, e-lane: sigma0)
+  bool a_lane;
+  u32 cv[4];                       // this lane's half of the chaining value: a-lane H0..H3, e-lane H4..H7
+  static MS_HD bool is_a_lane(int lane) { return (lane >> 2) & 1; }
+  // node index of a lane among the 4 nodes its group of eight lanes hashes (partners get the same index)
+  static MS_HD int node_in_group(int lane) { return is_a_lane(lane) ? 3 - (lane & 3) : (lane & 3); }
+  MS_DEV void init(int lane) {
+    a_lane = is_a_lane(lane);
+    M = a_lane ? ~0u : 0u;
+    R1 = a_lane ? 2 : 6; R2 = a_lane ? 13 : 11; R3 = a_lane ? 22 : 25;
+    Sa = a_lane ? 17 : 7; Sb = a_lane ? 19 : 18; Sc = a_lane ? 10 : 3;
+  }
+  MS_DEV void reset() {
+    cv[0] = a_lane ? 0x6a09e667u : 0x510e527fu; cv[1] = a_lane ? 0xbb67ae85u : 0x9b05688cu; cv[2] = a_lane ? 0x3c6ef372u : 0x1f83d9abu; cv[3] = a_lane ? 0xa54ff53au : 0x5be0cd19u;
+  }
+  // kw = K + W of the round (used by the e-lane only)
+  MS_DEV void round(u32& x, u32& y, u32& z, u32& v, u32 kw) const {
+    const u32 S = xor3(msrt::rotr_var(x, R1), msrt::rotr_var(x, R2), msrt::rotr_var(x, R3));
+    const u32 xp = ms_bitop3<0x78>(x, z, M);          // a ^ (b & c): the a-lane's a ^ c, the e-lane's e
+    const u32 F = ch3(xp, y, z);
+    const u32 s = S + F;                              // e-lane: Sigma1 + Ch; a-lane: T2
+    const u32 t = s + v + kw;                         // e-lane: T1
+    const u32 n = msrt::pair_exchange_add(a_lane, v, t, s);   // e-lane: d + T1 = the new e; a-lane: T1 + T2 = the new a
+    v = z; z = y; y = x; x = n;
+  }
+  // the 16 message words w (both lanes hold them all; clobbered)
+  MS_DEV void compress(u32 (&w)[16]) {
+    u32 x = cv[0], y = cv[1], z = cv[2], v = cv[3];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      if (i >= 16) {
+        const u32 r = ms_bitop3<0xE4>(w[(i + 14) & 15], w[(i + 1) & 15], M);   // c ? a : b - a-lane: W[i-2] (sigma1); e-lane: W[i-15] (sigma0)
+        const u32 o = ms_bitop3<0xE4>(w[(i + 9) & 15], w[i & 15], M);          // a-lane: W[i-7]; e-lane: W[i-16]
+        const u32 sig = xor3(msrt::rotr_var(r, Sa), msrt::rotr_var(r, Sb), r >> Sc);
+        const u32 p = sig + o;
+        w[i & 15] = p + msrt::pair_swap(p);
+      }
+      round(x, y, z, v, w[i & 15] + SHA_K[i]);
+    }
+    cv[0] += x; cv[1] += y; cv[2] += z; cv[3] += v;
+  }
+  template <u32 MSG_BITS> MS_DEV void compress_pad_block() {
+    u32 x = cv[0], y = cv[1], z = cv[2], v = cv[3];
+#pragma unroll
+    for (int i = 0; i < 64; i++) round(x, y, z, v, PadBlock<MSG_BITS>::T.kw[i]);
+    cv[0] += x; cv[1] += y; cv[2] += z; cv[3] += v;
+  }
+};
+
 // {hi, lo} >> sh (low word), sh in {0, 8, 16, 24}
 MS_HD u32 funnel_r(u32 hi, u32 lo, u32 sh) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -561,10 +616,55 @@ struct InnerSubtreeKernel {
     const u32 nl = p.nlevels;
     size_t child_off = p.child_off, nchildren = p.nchildren;
     u32 pp = 1u << nl;
+    Sha256Pair hp; hp.init(tid);
     for (u32 l = 0; l < nl; l++) {
       pp >>= 1;   // parents of this workgroup at this level
       const size_t nparents = nchildren >> 1;
-      if ((u32)tid < pp) {
+#ifndef MS_SUBTREE_PAIR_LEVELS
+#define MS_SUBTREE_PAIR_LEVELS 1   // 0 (tests, A/B): every level one parent per lane
+#endif
+      if (MS_SUBTREE_PAIR_LEVELS && 2 * pp <= (u32)THREADS) {
+        // at most half as many parents as lanes: one parent per PAIR of lanes (Sha256Pair), whole groups of eight lanes at work (4 parents each; with fewer than 4
+        // parents the spare pairs hash parent 0's children again and store nothing)
+        const u32 nact = 2 * pp < 8 ? 8 : 2 * pp;
+        if ((u32)tid < nact) {
+          const u32 nd0 = ((u32)tid >> 3) * 4 + (u32)Sha256Pair::node_in_group(tid);
+          const bool live = nd0 < pp;
+          const u32 nd = live ? nd0 : 0;
+          const size_t g = (size_t)bx * pp + nd;
+          u32 w[16];
+          if (l == 0) {
+            const uint4_t* c4 = reinterpret_cast<const uint4_t*>(p.nodes + (child_off + 2 * g) * 8);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const uint4_t v = c4[q];
+              w[4 * q] = bswap32(v.x); w[4 * q + 1] = bswap32(v.y); w[4 * q + 2] = bswap32(v.z); w[4 * q + 3] = bswap32(v.w);
+            }
+          } else {
+            const uint4_t* c4 = reinterpret_cast<const uint4_t*>(((l & 1) ? buf0 : buf1) + (size_t)nd * 16);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint4_t v = c4[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+          }
+          hp.reset();
+          hp.compress(w);
+          hp.template compress_pad_block<512u>();
+          const int half = hp.a_lane ? 0 : 1;   // the a-lane holds words 0..3 of the digest, the e-lane words 4..7
+          uint4_t sv; sv.x = hp.cv[0]; sv.y = hp.cv[1]; sv.z = hp.cv[2]; sv.w = hp.cv[3];
+          uint4_t ov; ov.x = bswap32(hp.cv[0]); ov.y = bswap32(hp.cv[1]); ov.z = bswap32(hp.cv[2]); ov.w = bswap32(hp.cv[3]);
+          const bool fwd = p.host_root && nparents == 1;   // (uniform) the root also goes to page-locked host memory, stored by ONE lane: the e-lane fetches the other half
+          uint4_t oth = ov;
+          if (fwd) { oth.x = msrt::pair_swap(ov.x); oth.y = msrt::pair_swap(ov.y); oth.z = msrt::pair_swap(ov.z); oth.w = msrt::pair_swap(ov.w); }
+          if (live) {
+            if (l + 1 < nl) reinterpret_cast<uint4_t*>(((l & 1) ? buf1 : buf0) + (size_t)nd * 8)[half] = sv;
+            reinterpret_cast<uint4_t*>(p.nodes + (child_off + nchildren + g) * 8)[half] = ov;
+            if (fwd && !hp.a_lane) {
+              uint4_t* hr = reinterpret_cast<uint4_t*>(p.host_root); hr[0] = oth; hr[1] = ov;
+              if (p.aux_src) { *p.aux_dst = *p.aux_src; *p.aux_src = 0; }
+              msrt::raise_host_flag(p.flag);
+            }
+          }
+        }
+      } else if ((u32)tid < pp) {
         const size_t g = (size_t)bx * pp + (u32)tid;
         Sha256 h; h.init();
         u32 w[16];

@@ -106,47 +106,114 @@ struct Sdma {
 };
 }  // namespace msrt
 // ---- cooperative kernels (K::run with workgroup barriers INSIDE the function, per-thread state alive across them): every thread of a
-// workgroup is a fiber (ucontext); wg_barrier() yields to the scheduler, which resumes the fibers round-robin, so all of them reach
-// barrier k before any runs past it.  wave_shfl_xor() & co. are workgroup-wide rendezvous points of the same kind that exchange
-// values inside each group of 64 consecutive threads - the emulated wave is 64 lanes wide, like the hardware's.
-#include <ucontext.h>
+// workgroup is a fiber (its own stack; fiber_switch below), resumed round-robin by the scheduler.  wg_barrier() is a real barrier over the fibers that have not
+// returned (as s_barrier is over the waves that have not ended); wave_shfl_xor() & co. are rendezvous of a lane with its PARTNER lane inside
+// each group of 64 consecutive threads (the emulated wave is 64 lanes wide, like the hardware's), so lanes that sit out a stretch of
+// exchanges - the idle lanes of the upper tree levels - do not have to mirror their partners' calls (r05; until then both were plain
+// yields, correct only while every fiber made every call).
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#endif
 namespace msrt {
+// Stack switch of the fibers (x86-64 SysV): callee-saved registers on the old stack, stack pointers exchanged, `ret` into the new one.  (glibc's swapcontext does the
+// same plus one sigprocmask system call per switch; since the lane-pair exchanges of the tree levels a proof switches fibers millions of times and the system calls were
+// a third of the CPU suite's time.)
+#if !defined(__x86_64__)
+#error "the kernel-emulation build switches fiber stacks with x86-64 assembly"
+#endif
+__attribute__((naked, noinline, unused)) static void fiber_switch(void** /*save_sp: rdi*/, void* /*to_sp: rsi*/) {
+  asm volatile("pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+               "movq %rsp, (%rdi)\n\tmovq %rsi, %rsp\n\t"
+               "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret");
+}
 struct FiberBlock {
   static constexpr size_t STACK = 96 << 10;
-  std::vector<ucontext_t> ctx; std::vector<unsigned char> stacks; std::vector<char> done; std::vector<unsigned long long> xchg;
-  ucontext_t sched; int cur = -1, nthreads = 0;
+  std::vector<void*> sp; std::vector<unsigned char> stacks; std::vector<char> done; std::vector<unsigned long long> xchg; std::vector<unsigned> shseq, rdseq; std::vector<int> shpart;
+  void* sched_sp = nullptr; int cur = -1, nthreads = 0;
+  int alive = 0, bar_arrived = 0; unsigned bar_gen = 0;
   void (*entry)(void*, int) = nullptr; void* arg = nullptr;
   static FiberBlock*& active() { static thread_local FiberBlock* a = nullptr; return a; }
-  static void trampoline() { FiberBlock* b = active(); const int t = b->cur; b->entry(b->arg, t); b->done[t] = 1; swapcontext(&b->ctx[t], &b->sched); }
-  void yield() { const int t = cur; swapcontext(&ctx[t], &sched); }
+  // (AddressSanitizer keeps per-thread stack bounds: it is told about every switch)
+  void to_fiber(int t) {
+#if defined(__SANITIZE_ADDRESS__)
+    void* fake = nullptr; __sanitizer_start_switch_fiber(&fake, stacks.data() + (size_t)t * STACK, STACK);
+    fiber_switch(&sched_sp, sp[t]);
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#else
+    fiber_switch(&sched_sp, sp[t]);
+#endif
+  }
+  void to_sched(int t, bool last) {
+#if defined(__SANITIZE_ADDRESS__)
+    void* fake = nullptr; __sanitizer_start_switch_fiber(last ? nullptr : &fake, sched_stack_bottom, sched_stack_size);
+    fiber_switch(&sp[t], sched_sp);
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#else
+    (void)last; fiber_switch(&sp[t], sched_sp);
+#endif
+  }
+#if defined(__SANITIZE_ADDRESS__)
+  const void* sched_stack_bottom = nullptr; size_t sched_stack_size = 0;
+#endif
+  static void trampoline() {
+    FiberBlock* b = active(); const int t = b->cur;
+#if defined(__SANITIZE_ADDRESS__)
+    __sanitizer_finish_switch_fiber(nullptr, &b->sched_stack_bottom, &b->sched_stack_size);
+#endif
+    b->entry(b->arg, t); b->done[t] = 1; b->alive--;
+    b->to_sched(t, true);
+    __builtin_unreachable();
+  }
+  void yield() { to_sched(cur, false); }
+  void barrier() {
+    const unsigned g = bar_gen;
+    bar_arrived++;
+    for (;;) {
+      if (bar_gen != g) return;
+      if (bar_arrived >= alive) { bar_arrived = 0; bar_gen++; return; }   // the last to arrive (or the others have returned) opens it
+      yield();
+    }
+  }
   void run_block(int threads, void (*fn)(void*, int), void* a) {
     nthreads = threads; entry = fn; arg = a;
-    if ((int)ctx.size() < threads) { ctx.resize(threads); stacks.resize((size_t)threads * STACK); }
-    done.assign(threads, 0); xchg.assign(threads, 0);
-    for (int t = 0; t < threads; t++) {
-      getcontext(&ctx[t]);
-      ctx[t].uc_stack.ss_sp = stacks.data() + (size_t)t * STACK; ctx[t].uc_stack.ss_size = STACK; ctx[t].uc_link = &sched;
-      makecontext(&ctx[t], (void (*)())trampoline, 0);
+    if ((int)sp.size() < threads) { sp.resize(threads); stacks.resize((size_t)threads * STACK + 64); }
+    done.assign(threads, 0); xchg.assign((size_t)threads * 2, 0); shseq.assign(threads, 0); rdseq.assign(threads, 0); shpart.assign((size_t)threads * 2, 0);
+    alive = threads; bar_arrived = 0; bar_gen = 0;
+    for (int t = 0; t < threads; t++) {   // a fresh stack: six zero registers under the address the first switch returns to; the entry sees rsp = 8 (mod 16), as after a call
+      uintptr_t top = (reinterpret_cast<uintptr_t>(stacks.data()) + (size_t)(t + 1) * STACK) & ~(uintptr_t)15;
+      void** w = reinterpret_cast<void**>(top);
+      *--w = nullptr;
+      *--w = reinterpret_cast<void*>(&trampoline);
+      for (int k = 0; k < 6; k++) *--w = nullptr;
+      sp[t] = w;
     }
     FiberBlock* prev = active(); active() = this;
     for (;;) {
       bool any = false;
-      for (int t = 0; t < threads; t++) if (!done[t]) { any = true; cur = t; swapcontext(&sched, &ctx[t]); }
+      for (int t = 0; t < threads; t++) if (!done[t]) { any = true; cur = t; to_fiber(t); }
       if (!any) break;
     }
     cur = -1; active() = prev;
   }
 };
-inline void wg_barrier() { FiberBlock::active()->yield(); }
-inline void wg_barrier_global() { FiberBlock::active()->yield(); }   // (the emulated workgroup's "global" memory is plain host memory: always coherent)
+inline void wg_barrier() { FiberBlock::active()->barrier(); }
+inline void wg_barrier_global() { FiberBlock::active()->barrier(); }   // (the emulated workgroup's "global" memory is plain host memory: always coherent)
 inline void fence_device() {}
 inline int wave_uniform(int v) { return v; }
-// value of lane (lane ^ mask) of the caller's 64-lane wave; every thread of the workgroup must call it (like __shfl_xor under full exec)
+// value of lane (lane ^ mask) of the caller's 64-lane wave; the partner lane must make the matching call (its k-th exchange with the caller's k-th: the lanes of a
+// wave run the same instruction stream).  Two slots per lane, written alternately: before a lane reuses a slot it waits until the partner of the exchange that used
+// it (two exchanges back; the partner changes from call to call in a butterfly) has read it.  A partner that has returned gives the caller's own value.
 inline unsigned long long wave_shfl_xor(unsigned long long v, int mask) {
   FiberBlock* b = FiberBlock::active(); const int t = b->cur;
-  b->xchg[t] = v; b->yield();
-  const unsigned long long r = b->xchg[(t & ~63) | ((t ^ mask) & 63)];
-  b->yield();                      // nobody overwrites its slot before every lane has read
+  const int pt = (t & ~63) | ((t ^ mask) & 63);
+  if (pt >= b->nthreads) return v;
+  const unsigned k = b->shseq[t];
+  const size_t slot = (size_t)t * 2 + (k & 1);
+  if (k >= 2) { const int old = b->shpart[slot]; while (b->rdseq[old] < k - 1 && !b->done[old]) b->yield(); }
+  b->xchg[slot] = v; b->shpart[slot] = pt; b->shseq[t] = k + 1;
+  while (b->shseq[pt] < k + 1) { if (b->done[pt]) { b->rdseq[t] = k + 1; return v; } b->yield(); }
+  const unsigned long long r = b->xchg[(size_t)pt * 2 + (k & 1)];
+  b->rdseq[t] = k + 1;
   return r;
 }
 template <class K> struct CoopArgs { const typename K::Params* p; int bx, by, nbx, threads; unsigned char* lds; };
@@ -169,6 +236,13 @@ MS_DEV unsigned atomic_add_u32(unsigned* a, unsigned v) { unsigned o = *a; *a = 
 MS_DEV unsigned wave_alloc_slot(unsigned* counter, bool want) { if (!want) return 0; unsigned o = *counter; *counter = o + 1; return o; }
 // true if the predicate holds on any live lane of the wave (emulation: a wave of one lane — results must not depend on it)
 MS_DEV bool wave_any(bool pred) { return pred; }
+// lane-pair exchanges of msmerkle::Sha256Pair (lane i and lane i ^ 7 of a group of eight; see the HIP forms below)
+inline unsigned pair_swap(unsigned v) { return (unsigned)wave_shfl_xor(v, 7); }
+inline unsigned pair_exchange_add(bool a_lane, unsigned v, unsigned t, unsigned s) {
+  const unsigned long long r = wave_shfl_xor((unsigned long long)v | ((unsigned long long)t << 32), 7);
+  return a_lane ? (unsigned)(r >> 32) + s : (unsigned)r + t;
+}
+inline unsigned rotr_var(unsigned x, unsigned r) { return (x >> r) | (x << ((32 - r) & 31)); }
 struct HostFlag { unsigned long long* dst; unsigned long long val; };
 MS_DEV void raise_host_flag(const HostFlag& f) { if (f.dst) *f.dst = f.val; }   // (an emulated launch has run to its end before the host looks)
 inline void raise_host_flag_wg(const HostFlag& f, int tid) { if (f.dst && tid == 0) *f.dst = f.val; }
@@ -519,6 +593,17 @@ MS_DEV unsigned wave_alloc_slot(unsigned* counter, bool want) {
   base = (unsigned)__shfl((int)base, leader);
   return base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
 }
+// Lane-pair exchanges of msmerkle::Sha256Pair: lane i and lane 7 - i (= i ^ 7) of every group of eight lanes are partners (DPP row_half_mirror); the lanes of banks
+// 0 and 2 of a 16-lane row (i & 4 == 0) hold the e-side of a round, those of banks 1 and 3 the a-side.
+MS_DEV unsigned pair_swap(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); }
+// e-lanes: partner's v + t; a-lanes: partner's t + s - two bank-masked DPP adds into one register.  The wait state between them (with the first add) makes the two a VALU
+// write of t needs before a DPP read of it; v is three rounds old.
+MS_DEV unsigned pair_exchange_add(bool, unsigned v, unsigned t, unsigned s) {
+  unsigned n;
+  asm("v_add_u32_dpp %0, %1, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\ts_nop 0\n\tv_add_u32_dpp %0, %2, %3 row_half_mirror row_mask:0xf bank_mask:0xa" : "=&v"(n) : "v"(v), "v"(t), "v"(s));
+  return n;
+}
+MS_DEV unsigned rotr_var(unsigned x, unsigned r) { return __builtin_amdgcn_alignbit(x, x, r); }
 // "this stage's results are in page-locked host memory": a sequence number the kernel that ends a stage stores BEHIND its results, for a host that polls the word
 // instead of synchronising with the stream (MS_FLAG_LATENCY: 6.4 instead of 11.0 us from launch to host-visible result, profiles/r05_latency_probe.txt).  Called by
 // the ONE thread that stored the results itself: system-scope fence (its stores have left for the host), then a system-scope release store of the word.

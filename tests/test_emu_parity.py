@@ -561,7 +561,8 @@ def test_copy_engine_failures_fail_closed(monkeypatch, field):
 
 
 @pytest.mark.parametrize("field", [0, 1])
-@pytest.mark.parametrize("log_n,blowup,tail_max,fused", [(8, 8, "0", False), (8, 8, "8192", True), (10, 8, "1048576", True), (9, 2, "1048576", True), (6, 16, "64", True), (11, 1, "4096", True)])
+@pytest.mark.parametrize("log_n,blowup,tail_max,fused", [(8, 8, "0", False), (8, 8, "8192", True), (10, 8, "1048576", True), (9, 2, "1048576", True), (6, 16, "64", True), (11, 1, "4096", True),
+                                                        (12, 4, None, True), (12, 8, "1048576", True)])
 def test_fri_tail_rounds_fused_and_launch_per_step(monkeypatch, field, log_n, blowup, tail_max, fused):
     """r05: a tail round of the FRI commit phase as ONE launch - fold, DEEP quotient, trimmed length, pointwise codeword, leaf digests with their
     pad-only blocks in place, every tree level, root and length to the host - against the oracle, forced off, at the default threshold and forced far up (several
