@@ -54,6 +54,15 @@ def test_merkle(mk, field, leaf_num, ext, lpn, ic):
 
 
 @pytest.mark.parametrize("field", [0, 1])
+def test_merkle_binary_tree_every_height(mk, field):
+    """r05: binary trees of 2 .. 2^16 leaf groups - every height the subtree kernel can be handed (one to nine levels per launch, one or two launches), hence every
+    width of the levels hashed by PAIRS of lanes (merkle.hpp Sha256Pair: 128 .. 1 parents per workgroup, whole and partial groups of eight lanes, the root's
+    two halves joined in one lane) next to the one-lane-per-node first level of a nine-level launch."""
+    for k in range(2, 18):
+        pc.case_merkle(mk, field, 1 << k, 1, 2, 2)
+
+
+@pytest.mark.parametrize("field", [0, 1])
 def test_prove_base_field_deep_points(mk, field):
     pc.case_prove_base_field_deep_points(mk, field)
 

@@ -62,6 +62,14 @@ def test_merkle(mk, field, leaf_num, ext, lpn, ic):
 
 
 @pytest.mark.parametrize("field", [0, 1])
+def test_merkle_binary_tree_every_height(mk, field):
+    """r05: binary trees of 2 .. 2^20 leaf groups against the oracle - every height the subtree kernel can be handed, hence every width of the levels hashed by
+    PAIRS of lanes (merkle.hpp Sha256Pair: bank-masked DPP adds under a partial EXEC mask, whole and partial groups of eight lanes) next to the one-lane-per-node levels."""
+    for k in range(2, 22):
+        pc.case_merkle(mk, field, 1 << k, 1, 2, 2)
+
+
+@pytest.mark.parametrize("field", [0, 1])
 def test_prove_base_field_deep_points(mk, field):
     pc.case_prove_base_field_deep_points(mk, field)
 
