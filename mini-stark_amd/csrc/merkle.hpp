@@ -136,6 +136,9 @@ struct Sha256 {
   }
 };
 
+#ifndef MS_SUBTREE_PAIR_LEVELS
+#define MS_SUBTREE_PAIR_LEVELS 1   // 0 (A/B builds): every level of InnerSubtreeKernel one parent per lane
+#endif
 // One inner node of the binary tree (64-byte message + its constant padding block) hashed by a PAIR of lanes (r05): the e-side (e, f, g, h) of a round in one lane,
 // the a-side (a, b, c, d) in its partner (msrt::pair_swap: lane ^ 7), as ONE instruction stream - per-lane rotation amounts, Maj(a, b, c) = Ch(a ^ c, b, c) so that one
 // bitop3 pair serves both, T1 and d exchanged by two bank-masked DPP adds, sigma0 / sigma1 of the message schedule split over the two lanes.  1800 VALU instructions per
@@ -602,7 +605,8 @@ typedef InnerHashKernelT<2> InnerHashKernel2;
 // node is written to its place in the level-major node array (the openings read them), but a level reads its children from LDS, as the state words the level
 // below left there (no byte swaps either), behind a barrier that orders LDS traffic only: a level costs 4.5 us (the two compressions of a lone wave: 4.1 us)
 // instead of the 6.0-6.3 us that one launch per level, or one workgroup walking the levels through global memory, took (r04 trace of one proof:
-// profiles/r04_small_round_kernels_ab.log).
+// profiles/r04_small_round_kernels_ab.log).  r05: from the level on where the workgroup has at most half as many parents as lanes, a parent is hashed by a PAIR of
+// lanes (Sha256Pair above): 3.4 us of compressions per level instead of 4.1.
 // nlevels <= MAX_LEVELS; grid = nchildren >> nlevels; host_root / aux as InnerHashKernelT.
 struct InnerSubtreeKernel {
   static constexpr int THREADS = msmerkle::THREADS;
@@ -620,9 +624,6 @@ struct InnerSubtreeKernel {
     for (u32 l = 0; l < nl; l++) {
       pp >>= 1;   // parents of this workgroup at this level
       const size_t nparents = nchildren >> 1;
-#ifndef MS_SUBTREE_PAIR_LEVELS
-#define MS_SUBTREE_PAIR_LEVELS 1   // 0 (tests, A/B): every level one parent per lane
-#endif
       if (MS_SUBTREE_PAIR_LEVELS && 2 * pp <= (u32)THREADS) {
         // at most half as many parents as lanes: one parent per PAIR of lanes (Sha256Pair), whole groups of eight lanes at work (4 parents each; with fewer than 4
         // parents the spare pairs hash parent 0's children again and store nothing)
