@@ -1,6 +1,7 @@
 // Lab (MI355X): one Merkle inner node (SHA-256 of 64 bytes + its constant padding block) hashed by a PAIR of lanes - the e-side (e, f, g, h) of a round in the even
 // lane, the a-side (a, b, c, d) in the odd one, as the same instruction stream with per-lane rotation amounts, Maj(a,b,c) = Ch(a ^ c, b, c), the message schedule's
-// sigma0 / sigma1 split over the two lanes, and one DPP add per exchange - against the one-lane-per-node formulation of csrc/merkle.hpp, as a DEPENDENT CHAIN of nodes
+// sigma0 / sigma1 split over the two lanes, and one DPP add per exchange (a local neighbour-lane form, and merkle.hpp's Sha256Pair) - against the one-lane-per-node
+// formulation of csrc/merkle.hpp, as a DEPENDENT CHAIN of nodes
 // in a lone wave (the situation of the upper tree levels: a level costs what one node costs).  Prints us per node for both, and checks they agree.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mini-stark_amd/csrc tools/sha_pair_lab.hip -o /tmp/sha_pair_lab && /tmp/sha_pair_lab
 #include "merkle.hpp"
@@ -76,7 +77,15 @@ template <int MODE> __global__ __launch_bounds__(64) void chain(u32* out, const 
     const msmerkle::uint4_t* c4 = reinterpret_cast<const msmerkle::uint4_t*>(slot);
 #pragma unroll
     for (int q = 0; q < 4; q++) { const msmerkle::uint4_t v = c4[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
-    if (PAIR) {
+    if (MODE == 2) {   // the product's formulation itself (merkle.hpp Sha256Pair: partners lane ^ 7, bank-masked DPP adds)
+      msmerkle::Sha256Pair hp; hp.init(lane);
+      hp.reset();
+      hp.compress(w);
+      hp.template compress_pad_block<512u>();
+      __syncthreads();
+      msmerkle::uint4_t o; o.x = hp.cv[0]; o.y = hp.cv[1]; o.z = hp.cv[2]; o.w = hp.cv[3];
+      reinterpret_cast<msmerkle::uint4_t*>(slot)[A ? 0 : 1] = o;
+    } else if (PAIR) {
       u32 cv[4];
       cv[0] = A ? 0x6a09e667u : 0x510e527fu; cv[1] = A ? 0xbb67ae85u : 0x9b05688cu; cv[2] = A ? 0x3c6ef372u : 0x1f83d9abu; cv[3] = A ? 0xa54ff53au : 0x5be0cd19u;
       pair_compress<MODE>(cv, w, c);
@@ -104,7 +113,7 @@ int main() {
   const int iters = 2000;
   float ms[3];
   u32* d2; hipMalloc(&d2, 64 * 8 * 4);
-  const char* names[3] = {"one lane per node                                     ", "lane pair (neighbours; two selects + one DPP add)     ", "lane pair (half-mirror; two bank-masked DPP adds, asm)"};
+  const char* names[3] = {"one lane per node                                     ", "lane pair (neighbours; two selects + one DPP add)     ", "lane pair (merkle.hpp Sha256Pair: half-mirror, asm)   "};
   for (int mode = 0; mode < 3; mode++) {
     for (int rep = 0; rep < 2; rep++) {
       hipEventRecord(e0);
