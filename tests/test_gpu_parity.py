@@ -735,7 +735,7 @@ def test_latency_flag_side_stream_same_proof(field, log_n):
         orc.set_threads(8)
     try:
         ctx = ms.Context(field, flags=ms.FLAG_ZERO_DISPLAY_EMPTY | ms.FLAG_LATENCY)
-        for _ in range(2):
+        for _ in range(1 if log_n >= 21 else 2):   # (2^21 rows: once - the oracle's proof is 20 s of the suite)
             pc.case_prove(lambda f, fresh=False: ctx, field, log_n, 8, read_big=False)
         ctx.close()
     finally:
